@@ -1,0 +1,167 @@
+/*
+ * mpa.h -- C ABI of libmpa_hip.so, the MI355X (gfx950) kernel library behind
+ * multipitch_architectures_amd.nn_models.
+ *
+ * The reference (christofw/multipitch_architectures) has no FFI of its own: its
+ * hot path is the Python class API of libdl/nn_models,
+ * and every heavy op is a torch.nn call that lowers to cuDNN/cuBLAS/ATen.  Each
+ * entry point below therefore names the torch.nn call site it replaces
+ * (file:line in /root/reference) instead of a reference FFI symbol.
+ *
+ * Conventions
+ *   - all tensors are fp32, contiguous, device pointers; activations NCHW with
+ *     dim2 = time frames, dim3 = frequency bins (hcqt_datasets.py:74-75)
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued, never synced
+ *   - no allocation inside: workspaces are sized by the *_workspace() helpers and
+ *     passed in; no global state
+ *   - return 0 on success, negative MPA_ERR_* otherwise (mpa_strerror())
+ */
+#ifndef MPA_H
+#define MPA_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPA_OK 0
+#define MPA_ERR_ARG (-1)
+#define MPA_ERR_LAUNCH (-2)
+#define MPA_ERR_UNSUPPORTED (-3)
+#define MPA_ERR_WORKSPACE (-4)
+
+#define MPA_ACT_NONE 0
+#define MPA_ACT_RELU 1
+#define MPA_ACT_LRELU 2
+#define MPA_ACT_SIGMOID 3
+
+const char* mpa_strerror(int code);
+int mpa_version(void);
+
+/* ------------------------------------------------------------------ convolution
+ * Replaces nn.Conv2d in double_conv (unet_cnns.py:49-59), conv1/prefilt_list
+ * (basic_cnns.py:371-387), conv2/conv3/conv4 heads (unet_cnns.py:538-557) and
+ * convP (unet_cnns.py:2311-2318).  Cross-correlation, zero padding.
+ * Implicit GEMM on v_mfma_f32_16x16x4_f32 (exact fp32).                         */
+typedef struct mpa_conv_desc {
+  int32_t B, Cin, H, W;     /* input  (B,Cin,H,W)                 */
+  int32_t Cout, kh, kw;     /* weight (Cout,Cin,kh,kw)            */
+  int32_t sh, sw, ph, pw;   /* stride, zero padding               */
+} mpa_conv_desc;
+
+/* number of floats of the packed filter bank used by fwd (mode 0) / bwd-data (mode 1) */
+int64_t mpa_conv2d_packed_floats(const mpa_conv_desc* d, int mode);
+/* repack (Cout,Cin,kh,kw) filters for fwd (mode 0) or, flipped+transposed, for bwd-data (mode 1) */
+int mpa_conv2d_pack(const mpa_conv_desc* d, int mode, const float* w, float* w_packed, void* stream);
+/* y = act(conv(x, w) + bias) ; bias may be NULL */
+int mpa_conv2d_fwd(const mpa_conv_desc* d, const float* x, const float* w_packed, const float* bias,
+                   float* y, int act, float slope, void* stream);
+/* dx = conv_transpose(dy, w)  (w_packed from mode 1) */
+int mpa_conv2d_bwd_data(const mpa_conv_desc* d, const float* dy, const float* w_packed, float* dx, void* stream);
+/* dw = sum_b,y,x dy * x ; db = sum dy (db may be NULL).  workspace bytes from the helper. */
+int64_t mpa_conv2d_bwd_weight_workspace(const mpa_conv_desc* d);
+int mpa_conv2d_bwd_weight(const mpa_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
+                          void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ normalisation
+ * Input LayerNorm([C,F]) applied on x.transpose(1,2) (unet_cnns.py:505,560;
+ * basic_cnns.py:160,190): every (b,t) slice of C*F values is normalised jointly. */
+int mpa_layernorm_cf_fwd(const float* x, const float* w, const float* b, float* y, float* mean, float* rstd,
+                         int B, int C, int T, int F, float eps, void* stream);
+/* bytes of the dw/db partial-sum workspace of both LayerNorm backward kernels (n = number of affine elements) */
+int64_t mpa_layernorm_bwd_workspace(int n);
+int mpa_layernorm_cf_bwd_ws(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                            float* dx /*nullable*/, float* dw, float* db, void* ws, int B, int C, int T, int F, void* stream);
+/* LayerNorm over the last dim of (rows,E) with fused residual: y = LN(a + r) (unet_cnns.py:156,158) */
+int mpa_layernorm_rows_fwd(const float* a, const float* r /*nullable*/, const float* w, const float* b, float* sum_out,
+                           float* y, float* mean, float* rstd, int64_t rows, int E, float eps, void* stream);
+int mpa_layernorm_rows_bwd_ws(const float* dy, const float* xs, const float* w, const float* mean, const float* rstd,
+                              float* dx, float* dw, float* db, void* ws, int64_t rows, int E, void* stream);
+
+/* nn.BatchNorm2d + nn.ReLU of double_conv (unet_cnns.py:51-52,55-56).
+ * train: batch statistics (biased var), running stats updated with momentum (unbiased var);
+ * stats workspace: 2*C doubles (zeroed inside). relu!=0 fuses the ReLU.                        */
+int mpa_bn_relu_train_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
+                          float* running_var, int64_t* num_batches_tracked /*nullable, += 1*/, float* y, float* save_mean,
+                          float* save_invstd, double* stats_ws, int B, int C, int HW, float momentum, float eps, int relu,
+                          void* stream);
+int mpa_bn_relu_eval_fwd(const float* x, const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, float* y, float* save_mean /*nullable*/, float* save_invstd /*nullable*/,
+                         int B, int C, int HW, float eps, int relu, void* stream);
+/* dx, dgamma, dbeta from dy (grad w.r.t. the post-ReLU output y). train!=0: batch-stat backward. */
+int mpa_bn_relu_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean,
+                    const float* save_invstd, float* dx, float* dgamma, float* dbeta, double* stats_ws,
+                    int B, int C, int HW, int relu, int train, void* stream);
+
+/* ------------------------------------------------------------------ pooling / upsampling
+ * nn.MaxPool2d (unet_cnns.py:511-526; basic_cnns.py:376,393; unet_cnns.py:2314): -inf padding, floor mode.
+ * idx holds the flat input offset (within the H*W plane) of each window's first maximum.              */
+int mpa_maxpool2d_fwd(const float* x, float* y, int32_t* idx, int B, int C, int H, int W, int kh, int kw,
+                      int sh, int sw, int ph, int pw, void* stream);
+int mpa_maxpool2d_bwd(const float* dy, const int32_t* idx, float* dx, int B, int C, int H, int W, int kh, int kw,
+                      int sh, int sw, int ph, int pw, void* stream);
+/* unet_up_concat_padding (unet_cnns.py:93-104): out = cat([skip, pad(bilinear_x2_align_corners(x1))], dim=1) */
+int mpa_upcat_fwd(const float* x1, const float* skip, float* out, int B, int C1, int H1, int W1, int Cs, int Hs,
+                  int Ws, void* stream);
+int mpa_upcat_bwd(const float* dout, float* dx1, float* dskip, int B, int C1, int H1, int W1, int Cs, int Hs,
+                  int Ws, void* stream);
+
+/* ------------------------------------------------------------------ pointwise
+ * nn.LeakyReLU / nn.ReLU / nn.Sigmoid / nn.Dropout / residual adds                                         */
+int mpa_act_fwd(const float* x, float* y, int64_t n, int act, float slope, void* stream);
+int mpa_act_bwd(const float* dy, const float* x, float* dx, int64_t n, int act, float slope, void* stream);
+int mpa_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
+int mpa_add(const float* a, const float* b, float* y, int64_t n, void* stream);
+int mpa_axpy(float alpha, const float* x, float* y, int64_t n, void* stream);           /* y += alpha*x */
+int mpa_scale(float alpha, float* x, int64_t n, void* stream);
+int mpa_scale_by(const float* x, const float* g /*device scalar*/, float* y, int64_t n, void* stream);
+/* x (B,E,S) <-> (B,S,E) transposes of transformer_enc_layer.forward (unet_cnns.py:150,159); pe nullable (S,E) */
+/* x (B,R,Cc) -> y (B,Cc,R); pe_mode 0: none, 1: add pe (Cc,R) to the output, 2: add pe (R,Cc) to the input */
+int mpa_transpose_add(const float* x, const float* pe, float* y, int B, int R, int Cc, int pe_mode, void* stream);
+/* per-channel sum over (B,HW): conv bias gradient */
+int mpa_channel_sum(const float* x, float* out, int B, int C, int HW, void* stream);
+/* broadcast positional encoding add: y[b,s,:] = x[b,s,:] + pe[s,:] */
+int mpa_add_rows_bcast(const float* x, const float* pe, float* y, int B, int64_t SE, void* stream);
+
+/* ------------------------------------------------------------------ GEMM (nn.Linear, LSTM projections)
+ * C[M,N] (+)= A[M,K] * op(B) (+ bias[N]) with act; A(m,k)=A[m*lda_m+k*lda_k], B(k,n)=Bm[k*ldb_k+n*ldb_n]. */
+int mpa_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float* Bm, int64_t ldb_k, int64_t ldb_n,
+             const float* bias, float* C, int64_t ldc, int M, int N, int K, int accumulate, int act, void* stream);
+/* column sums of a (rows, N) matrix (Linear bias gradients) */
+int mpa_colsum(const float* x, float* out, int64_t rows, int N, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------ attention over the batch axis
+ * nn.MultiheadAttention fed (B,S,E) with batch_first=False (unet_cnns.py:134,153):
+ * for every position s and head, softmax((q*d^-1/2) k^T) over the B samples.  q,k,v,o: (B,S,E).           */
+int mpa_attn_batchaxis_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B, int S,
+                           int E, int heads, void* stream);
+int mpa_attn_batchaxis_bwd(const float* q, const float* k, const float* v, const float* o, const float* lse,
+                           const float* do_, float* dq, float* dk, float* dv, int B, int S, int E, int heads,
+                           void* stream);
+
+/* ------------------------------------------------------------------ LSTM cell (nn.LSTM, unet_cnns.py:232)
+ * gates (B,4H) pre-activations in order i,f,g,o; c_prev nullable (zeros).                                  */
+int mpa_lstm_cell_fwd(const float* gates, int64_t g_stride, const float* c_prev, float* c, float* h, int64_t h_stride,
+                      float* acts, int B, int H, void* stream);
+int mpa_lstm_cell_bwd(const float* dh, int64_t dh_stride, const float* dh_rec /*nullable*/, const float* dc_next /*nullable*/,
+                      const float* acts, const float* c_prev, const float* c, float* dgates, int64_t dg_stride,
+                      float* dc_prev, int B, int H, void* stream);
+
+/* ------------------------------------------------------------------ losses (caller side, exp126a...py:87; exp195f...py:331-334)
+ * BCELoss(mean) on probabilities with the -100 clamp; loss_out[0] += sum / n (zero it first).               */
+int mpa_bce_fwd(const float* p, const float* y, float* loss_out, int64_t n, void* stream);
+/* dp = g[0] * d(mean BCE)/dp ; g is a device scalar (the upstream gradient), nullable = 1 */
+int mpa_bce_bwd(const float* p, const float* y, float* dp, int64_t n, const float* g, void* stream);
+/* CrossEntropyLoss(mean) over rows of (B,K) logits with int64 targets; loss_out[0] += scale*mean.            */
+int mpa_ce_fwd_bwd(const float* logits, const int64_t* target, float* loss_out, float* dlogits, int B, int K,
+                   float scale, void* stream);
+
+/* ------------------------------------------------------------------ AdamW (exp126a...py:103-108,293)
+ * multi-tensor step: tensor lists as device-resident pointer tables.                                          */
+int mpa_adamw_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                   const int64_t* sizes, int ntensors, int64_t max_size, double lr, double beta1, double beta2,
+                   double eps, double weight_decay, int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

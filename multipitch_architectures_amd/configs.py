@@ -1,0 +1,66 @@
+"""Experiment -> (model class, constructor kwargs) table.
+
+Restates the ``model_params`` dicts of the reference's experiment scripts
+(experiments/Exp1_SectionIV-B/exp*.py:73-86 each).  The
+"tiny" entries are build-side reductions of the same classes used to keep CPU
+parity tests fast; they exist in no experiment script.
+"""
+
+_COMMON = dict(n_chan_input=6, n_bins_in=216, n_bins_out=72, a_lrelu=0.3, p_dropout=0.2)
+
+
+def _c(cls, lr=1e-3, **kw):
+    d = dict(_COMMON)
+    d.update(kw)
+    return {"cls": cls, "kwargs": d, "lr": lr}
+
+
+CONFIGS = {
+    # paper name      class                                   kwargs
+    "CNN:XS": _c("basic_cnn_segm_sigmoid", n_chan_layers=[20, 20, 10, 1]),                       # exp126a
+    "CNN:S": _c("basic_cnn_segm_sigmoid", n_chan_layers=[100, 100, 50, 10]),                     # exp126b
+    "DCNN:S": _c("deep_cnn_segm_sigmoid", n_chan_layers=[20, 20, 10, 1], n_prefilt_layers=5, residual=False),  # exp127a
+    "DRCNN:S": _c("deep_cnn_segm_sigmoid", n_chan_layers=[20, 20, 10, 1], n_prefilt_layers=5, residual=True),  # exp128a
+    "DRCNN:L": _c("deep_cnn_segm_sigmoid", lr=2e-4, n_chan_layers=[70, 70, 50, 10], n_prefilt_layers=5, residual=True),  # exp128c
+    "Unet:S": _c("simple_u_net_largekernels", n_chan_layers=[64, 30, 20, 10], scalefac=8),       # exp160d2
+    "Unet:L": _c("simple_u_net_largekernels", n_chan_layers=[128, 150, 100, 80], scalefac=4),    # exp160e3
+    "SAUnet:M": _c("simple_u_net_doubleselfattn", n_chan_layers=[64, 30, 20, 10], scalefac=8, embed_dim=64,
+                   num_heads=8, mlp_dim=1024, pos_encoding="sinusoidal"),                        # exp180b
+    "SAUnet:L": _c("simple_u_net_doubleselfattn", n_chan_layers=[128, 80, 50, 30], scalefac=4, embed_dim=128,
+                   num_heads=8, mlp_dim=8192, pos_encoding="sinusoidal"),                        # exp180d
+    "SAUSnet:L": _c("simple_u_net_doubleselfattn_twolayers", n_chan_layers=[128, 80, 50, 30], scalefac=4,
+                    embed_dim=128, num_heads=8, mlp_dim=4096, pos_encoding="sinusoidal"),        # exp181d
+    "BLUnet:M": _c("u_net_blstm_varlayers", n_chan_layers=[64, 30, 20, 10], scalefac=16, embed_dim=416,
+                   hidden_size=208, lstm_depth=1, lstm_number=1),                                # exp186b
+    "BLUnet:L": _c("u_net_blstm_varlayers", n_chan_layers=[128, 80, 50, 30], scalefac=8, embed_dim=832,
+                   hidden_size=416, lstm_depth=1, lstm_number=2),                                # exp186d
+    "BLUnet:XXL": _c("u_net_blstm_varlayers", n_chan_layers=[128, 200, 150, 150], scalefac=4, embed_dim=1664,
+                     hidden_size=832, lstm_depth=1, lstm_number=1),                              # exp186e
+    "PUnet:M": _c("simple_u_net_polyphony_classif_softmax", n_chan_layers=[128, 100, 80, 50], scalefac=8,
+                  num_polyphony_steps=24),                                                       # exp195g
+    "PUnet:XL": _c("simple_u_net_polyphony_classif_softmax", n_chan_layers=[128, 180, 150, 100], scalefac=2,
+                   num_polyphony_steps=24),                                                      # exp195f
+    # ---- build-side reductions for fast parity tests (same classes, small channel counts)
+    "tiny:CNN": _c("basic_cnn_segm_sigmoid", n_chan_layers=[6, 8, 6, 4]),
+    "tiny:DRCNN": _c("deep_cnn_segm_sigmoid", n_chan_layers=[6, 8, 6, 4], n_prefilt_layers=3, residual=True),
+    "tiny:Unet": _c("simple_u_net_largekernels", n_chan_layers=[8, 8, 6, 4], scalefac=16),
+    "tiny:SAUnet": _c("simple_u_net_doubleselfattn", n_chan_layers=[8, 8, 6, 4], scalefac=16, embed_dim=32,
+                      num_heads=8, mlp_dim=64, pos_encoding="sinusoidal"),
+    "tiny:SAUnet-res": _c("simple_u_net_doubleselfattn", n_chan_layers=[8, 8, 6, 4], scalefac=16, embed_dim=32,
+                          num_heads=4, mlp_dim=48, pos_encoding=None, residual=True),
+    "tiny:SAUSnet": _c("simple_u_net_doubleselfattn_twolayers", n_chan_layers=[8, 8, 6, 4], scalefac=16,
+                       embed_dim=32, num_heads=8, mlp_dim=64, pos_encoding="sinusoidal"),
+    "tiny:BLUnet": _c("u_net_blstm_varlayers", n_chan_layers=[8, 8, 6, 4], scalefac=16, embed_dim=416,
+                      hidden_size=208, lstm_depth=1, lstm_number=2),
+    "tiny:PUnet": _c("simple_u_net_polyphony_classif_softmax", n_chan_layers=[8, 8, 6, 4], scalefac=16,
+                     num_polyphony_steps=24),
+}
+
+# BASELINE.json "configs" -> (paper name, batch) for bench/parity sizing
+BASELINE_CONFIGS = [("CNN:XS", 8), ("DRCNN:L", 64), ("Unet:L", 128), ("SAUnet:L", 256), ("BLUnet:XXL", 256)]
+
+# algorithmic train-step GFLOP per patch at T=75 (fwd+dgrad+wgrad)
+TRAIN_GFLOP_PER_PATCH = {"DRCNN:L": 436.32, "Unet:L": 88.25, "SAUnet:L": 86.67, "BLUnet:XXL": 91.01,
+                         "PUnet:XL": 243.93}
+FWD_GMAC_PER_PATCH = {"CNN:XS": 0.458, "DRCNN:L": 73.230, "Unet:L": 14.825, "SAUnet:L": 14.562,
+                      "BLUnet:XXL": 15.285, "PUnet:XL": 40.888}

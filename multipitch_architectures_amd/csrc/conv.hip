@@ -1,0 +1,591 @@
+// Implicit-GEMM 2-D convolution for gfx950 on v_mfma_f32_16x16x4_f32 (exact fp32).
+//
+// Replaces nn.Conv2d at: double_conv (unet_cnns.py:49-59), conv1/prefilt_list
+// (basic_cnns.py:371-387), conv2/conv3/conv4 (unet_cnns.py:538-557), convP (:2311-2318).
+//
+// Forward   D[cout][pixel] = sum_k Wp[cout][k] * X[k][pixel],  k = (cin, dy, dx)
+//   MFMA A operand = filters (m = cout), B operand = input halo tile in LDS
+//   (n = pixel), so the accumulator's lane index runs along pixels -> coalesced
+//   NCHW stores.  One block = 4 waves; a wave owns NB cout-blocks x PB
+//   pixel-blocks of 16x16.  The input tile (CK channels + halo) is staged once
+//   per channel chunk, the filter slab (one dy row: kw*CK*COT floats) once per
+//   (chunk, dy).
+// Backward-data = forward with flipped / transposed filters (pack mode 1).
+// Backward-weight: dW[cout][n] = sum_pixel dY[cout][pixel] * X[pixel][n],
+//   n = (cin,dy,dx) flattened; A = dY tile, B = shifted input tile, blocks loop
+//   over (image, tile) pairs and keep dW slices in registers; partials are
+//   reduced by a second kernel (deterministic, no atomics).
+#include "mpa_common.h"
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ planning
+struct FwdPlan {
+  int NB, PB, TH, TW, tilesY, tilesX, CK, nChunks, IH, IW, LW, CHP, COT, COTP, coTiles, OH, OW;
+  size_t lds_bytes;
+  bool ok;
+};
+
+inline int round_mod(int v, int m, int r) {  // smallest x >= v with x % m == r
+  int x = v + ((r - v % m) % m + m) % m;
+  return x;
+}
+
+FwdPlan plan_fwd(int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw) {
+  FwdPlan best{};
+  best.ok = false;
+  const int OH = (H + 2 * ph - kh) / sh + 1, OW = (W + 2 * pw - kw) / sw + 1;
+  if (OH <= 0 || OW <= 0) return best;
+  // cout blocking
+  const int nbs[4] = {1, 2, 4, 5};
+  int NB = 1;
+  long bestpad = -1;
+  for (int i = 0; i < 4; ++i) {
+    int cot = nbs[i] * 16;
+    long pad = (long)mpa_cdiv(Cout, cot) * cot;
+    if (bestpad < 0 || pad < bestpad || (pad == bestpad && nbs[i] > NB)) { bestpad = pad; NB = nbs[i]; }
+  }
+  const int COT = NB * 16;
+  const int COTP = (COT % 32 == 0) ? COT + 16 : COT;   // filter-slab pitch == 16 (mod 32): conflict-free A reads
+  const int cin4 = (int)mpa_cdiv(Cin, 4) * 4;
+  double bestcost = 1e300;
+  const int pbs[4] = {1, 2, 4, 6};
+  for (int pi = 0; pi < 4; ++pi) {
+    const int PB = pbs[pi], P = PB * 64;
+    for (int TH = 1; TH <= std::min(OH, P); ++TH) {
+      int TW = std::min(OW, P / TH);
+      if (TW < 1) continue;
+      // shrink TW so that tiles divide OW evenly
+      int tx = (int)mpa_cdiv(OW, TW);
+      TW = (int)mpa_cdiv(OW, tx);
+      const int ty = (int)mpa_cdiv(OH, TH);
+      const int IH = (TH - 1) * sh + kh, IW = (TW - 1) * sw + kw;
+      int LW = (sw == 1 && kw - 1 <= 32) ? TW + 32 : IW;      // row pitch == TW (mod 32): wrapped pixel blocks stay conflict-free
+      if (LW < IW) LW = IW;
+      const int CHP = round_mod(IH * LW, 32, 16);
+      // channel chunk
+      int CK = 4;
+      while (CK < 32 && CK < cin4 && kw * (CK / 4) < 15) CK *= 2;
+      while (CK > 4 && (size_t)(CK * CHP + kw * CK * COTP) * 4 > 64 * 1024) CK /= 2;
+      const size_t lds = (size_t)(CK * CHP + kw * CK * COTP) * 4;
+      if (lds > 64 * 1024) continue;
+      double cost = (double)ty * tx * P * (1.0 + 0.05 * IH * IW / P + 0.15 * (NB + PB) / (double)(NB * PB));
+      if (cost < bestcost) {
+        bestcost = cost;
+        best = FwdPlan{NB, PB, TH, TW, ty, tx, CK, (int)mpa_cdiv(Cin, CK), IH, IW, LW, CHP, COT, COTP,
+                       (int)mpa_cdiv(Cout, COT), OH, OW, lds, true};
+      }
+    }
+  }
+  return best;
+}
+
+__device__ __forceinline__ void fast_divmod(int idx, int d, float inv, int& q, int& r) {
+  q = (int)((float)idx * inv);
+  r = idx - q * d;
+  if (r < 0) { q -= 1; r += d; }
+  else if (r >= d) { q += 1; r -= d; }
+}
+
+// Stage a (nch x nrows x ncols) window of an NCHW image plane set into LDS, zero-filling outside the image.
+// dst[ch*chp + iy*lw + ix] = src[(c0+ch), y0+iy, x0+ix]
+__device__ __forceinline__ void stage_window(float* __restrict__ dst, const float* __restrict__ src, int tid, int nch,
+                                             int nrows, int ncols, int chp, int lw, int c0, int y0, int x0, int C, int H,
+                                             int W, int xlim) {
+  const int total = nch * nrows * ncols;
+  const float inv_c = 1.0f / (float)ncols, inv_r = 1.0f / (float)nrows;
+  for (int base = tid; base < total; base += 256 * 4) {
+    float v[4];
+    int o[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = base + u * 256;
+      v[u] = 0.f;
+      o[u] = -1;
+      if (idx < total) {
+        int row, ix, ch, iy;
+        fast_divmod(idx, ncols, inv_c, row, ix);
+        fast_divmod(row, nrows, inv_r, ch, iy);
+        const int gc = c0 + ch, gy = y0 + iy, gx = x0 + ix;
+        o[u] = ch * chp + iy * lw + ix;
+        if (gc < C && gy >= 0 && gy < H && gx >= 0 && gx < xlim) v[u] = src[((long)gc * H + gy) * W + gx];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (o[u] >= 0) dst[o[u]] = v[u];
+  }
+}
+
+struct ConvFwdParams {
+  const float* x;
+  const float* wp;
+  const float* bias;
+  float* y;
+  int B, Cin, H, W, Cout, OH, OW, kh, kw, sh, sw, ph, pw;
+  int TH, TW, tilesY, tilesX, CK, nChunks, IH, IW, LW, CHP, COT, COTP;
+  int act;
+  float slope;
+  long outBS, outCS;   // output batch / channel strides (floats)
+  int outRS, outXmul, outCdiv;
+};
+
+// ------------------------------------------------------------------------------------------------ forward kernel
+template <int NB, int PB>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* lds_in = lds;
+  float* lds_w = lds + p.CK * p.CHP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = blockIdx.x;
+  const int tx = bid % p.tilesX;
+  bid /= p.tilesX;
+  const int ty = bid % p.tilesY;
+  const int b = bid / p.tilesY;
+  const int cot = blockIdx.y;
+  const int oy0 = ty * p.TH, ox0 = tx * p.TW;
+  const int iy0 = oy0 * p.sh - p.ph, ix0 = ox0 * p.sw - p.pw;
+  const int npix = p.TH * p.TW;
+  const int kq = lane >> 4, l16 = lane & 15;
+
+  int boff[PB];
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb) {
+    int pix = (wave * PB + pb) * 16 + l16;
+    int pc = pix < npix ? pix : npix - 1;
+    int py = pc / p.TW, px = pc - py * p.TW;
+    boff[pb] = kq * p.CHP + py * p.sh * p.LW + px * p.sw;
+  }
+  const int aoff = kq * p.COTP + l16;
+  f32x4 acc[NB][PB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int j = 0; j < PB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const float* xb = p.x + (long)b * p.Cin * p.H * p.W;
+  const int slab = p.kw * p.CK * p.COTP;
+  const float* wtile = p.wp + (long)cot * p.nChunks * p.kh * slab;
+  const int astep = p.CK * p.COTP;
+
+  for (int c = 0; c < p.nChunks; ++c) {
+    __syncthreads();
+    stage_window(lds_in, xb, tid, p.CK, p.IH, p.IW, p.CHP, p.LW, c * p.CK, iy0, ix0, p.Cin, p.H, p.W, p.W);
+    for (int dy = 0; dy < p.kh; ++dy) {
+      if (dy > 0) __syncthreads();
+      {
+        const float4* ws = reinterpret_cast<const float4*>(wtile + (long)(c * p.kh + dy) * slab);
+        float4* wd = reinterpret_cast<float4*>(lds_w);
+        for (int i = tid; i < slab / 4; i += 256) wd[i] = ws[i];
+      }
+      __syncthreads();
+      for (int j = 0; j < p.CK / 4; ++j) {
+        const float* ap = lds_w + j * 4 * p.COTP + aoff;
+        const float* bp = lds_in + j * 4 * p.CHP + dy * p.LW;
+#pragma unroll 3
+        for (int dx = 0; dx < p.kw; ++dx) {
+          float a[NB], bv[PB];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) a[nb] = ap[dx * astep + nb * 16];
+#pragma unroll
+          for (int pb = 0; pb < PB; ++pb) bv[pb] = bp[boff[pb] + dx];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb)
+              acc[nb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nb], bv[pb], acc[nb][pb], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // epilogue: lane holds 4 consecutive couts (rows) of one pixel (column)
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb) {
+    const int pix = (wave * PB + pb) * 16 + l16;
+    if (pix >= npix) continue;
+    const int py = pix / p.TW, px = pix - py * p.TW;
+    const int oy = oy0 + py, ox = ox0 + px;
+    if (oy >= p.OH || ox >= p.OW) continue;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = cot * p.COT + nb * 16 + kq * 4 + r;
+        if (co >= p.Cout) continue;
+        float v = acc[nb][pb][r];
+        if (p.bias) v += p.bias[co];
+        v = mpa_apply_act(v, p.act, p.slope);
+        const int q = co / p.outCdiv, cc = co - q * p.outCdiv;
+        p.y[(long)b * p.outBS + (long)cc * p.outCS + (long)oy * p.outRS + (long)ox * p.outXmul + q] = v;
+      }
+    }
+  }
+}
+
+template <int NB>
+int launch_fwd_nb(const FwdPlan& pl, const ConvFwdParams& p, hipStream_t s) {
+  dim3 grid((unsigned)(p.B * pl.tilesY * pl.tilesX), (unsigned)pl.coTiles);
+  switch (pl.PB) {
+    case 1: hipLaunchKernelGGL((conv_fwd_kernel<NB, 1>), grid, dim3(256), pl.lds_bytes, s, p); break;
+    case 2: hipLaunchKernelGGL((conv_fwd_kernel<NB, 2>), grid, dim3(256), pl.lds_bytes, s, p); break;
+    case 4: hipLaunchKernelGGL((conv_fwd_kernel<NB, 4>), grid, dim3(256), pl.lds_bytes, s, p); break;
+    case 6: hipLaunchKernelGGL((conv_fwd_kernel<NB, 6>), grid, dim3(256), pl.lds_bytes, s, p); break;
+    default: return MPA_ERR_UNSUPPORTED;
+  }
+  return mpa_launch_status();
+}
+
+int launch_fwd(const FwdPlan& pl, const ConvFwdParams& p, hipStream_t s) {
+  switch (pl.NB) {
+    case 1: return launch_fwd_nb<1>(pl, p, s);
+    case 2: return launch_fwd_nb<2>(pl, p, s);
+    case 4: return launch_fwd_nb<4>(pl, p, s);
+    case 5: return launch_fwd_nb<5>(pl, p, s);
+    default: return MPA_ERR_UNSUPPORTED;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ filter packing
+// packed[cot][chunk][dy][dx][ck][COTP]
+//   mode 0 (forward)      : value = w[co][ci][dy][dx]
+//   mode 1 (backward-data): the derived conv has Cin' = Cout, Cout' = Cin (stride 1) or kw*Cin (stride == kernel
+//                           along W), value = w[ci'][co' % Cin][kh-1-dy][dxsel]
+struct PackParams {
+  const float* w;
+  float* wp;
+  int Cout_w, Cin_w, kh_w, kw_w;   // original filter dims
+  int mode, xphase;                // xphase: strided-W backward (dx taken from co' / Cin)
+  int CinP, CoutP, kh, kw;         // dims of the conv that will consume the packed filters
+  int CK, nChunks, COT, COTP, coTiles;
+  long total;
+};
+
+__global__ void conv_pack_kernel(const PackParams p) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < p.total; i += (long)gridDim.x * blockDim.x) {
+    long r = i;
+    const int col = (int)(r % p.COTP); r /= p.COTP;
+    const int ck = (int)(r % p.CK); r /= p.CK;
+    const int dx = (int)(r % p.kw); r /= p.kw;
+    const int dy = (int)(r % p.kh); r /= p.kh;
+    const int chunk = (int)(r % p.nChunks); r /= p.nChunks;
+    const int cot = (int)r;
+    const int co = cot * p.COT + col, ci = chunk * p.CK + ck;
+    float v = 0.f;
+    if (col < p.COT && co < p.CoutP && ci < p.CinP) {
+      if (p.mode == 0) {
+        v = p.w[(((long)co * p.Cin_w + ci) * p.kh_w + dy) * p.kw_w + dx];
+      } else if (!p.xphase) {
+        v = p.w[(((long)ci * p.Cin_w + co) * p.kh_w + (p.kh_w - 1 - dy)) * p.kw_w + (p.kw_w - 1 - dx)];
+      } else {
+        const int q = co / p.Cin_w, cc = co - q * p.Cin_w;   // q = dx phase
+        v = p.w[(((long)ci * p.Cin_w + cc) * p.kh_w + (p.kh_w - 1 - dy)) * p.kw_w + q];
+      }
+    }
+    p.wp[i] = v;
+  }
+}
+
+// derived problem for backward-data
+struct BwdDataGeom {
+  bool ok, xphase;
+  int Cin, H, W, Cout, kh, kw, ph, pw;   // stride-1 conv consuming dy (B,Cin=Cout_orig,H=OH,W=OW)
+};
+
+BwdDataGeom bwd_data_geom(const mpa_conv_desc* d) {
+  BwdDataGeom g{};
+  const int OH = (d->H + 2 * d->ph - d->kh) / d->sh + 1, OW = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
+  g.Cin = d->Cout; g.H = OH; g.W = OW;
+  if (d->sh == 1 && d->sw == 1) {
+    g.ok = true; g.xphase = false;
+    g.Cout = d->Cin; g.kh = d->kh; g.kw = d->kw; g.ph = d->kh - 1 - d->ph; g.pw = d->kw - 1 - d->pw;
+  } else if (d->sh == 1 && d->sw == d->kw && d->pw == 0 && OW * d->sw == d->W) {
+    g.ok = true; g.xphase = true;       // non-overlapping windows along W: kw independent (kh x 1) convs
+    g.Cout = d->kw * d->Cin; g.kh = d->kh; g.kw = 1; g.ph = d->kh - 1 - d->ph; g.pw = 0;
+  } else {
+    g.ok = false;
+  }
+  return g;
+}
+
+// ------------------------------------------------------------------------------------------------ backward-weight
+struct WgPlan {
+  int NBC, NTW, COT, coTiles, nPerBlock, nTiles, Ntot, XCH, TH, TW, DP, tilesY, tilesX, IH, IW, LW, XCHP, DCP, S, OH, OW;
+  size_t lds_bytes;
+  bool ok;
+};
+
+WgPlan plan_wgrad(const mpa_conv_desc* d) {
+  WgPlan pl{};
+  pl.ok = false;
+  const int OH = (d->H + 2 * d->ph - d->kh) / d->sh + 1, OW = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
+  if (OH <= 0 || OW <= 0) return pl;
+  const int khkw = d->kh * d->kw;
+  pl.OH = OH; pl.OW = OW;
+  pl.Ntot = d->Cin * khkw;
+  {
+    const int nbs[4] = {1, 2, 4, 5}, ntw[4] = {16, 8, 6, 6};
+    long bestpad = -1;
+    for (int i = 0; i < 4; ++i) {
+      const long pad = mpa_cdiv(d->Cout, nbs[i] * 16) * nbs[i] * 16;
+      if (bestpad < 0 || pad < bestpad || (pad == bestpad && nbs[i] > pl.NBC)) { bestpad = pad; pl.NBC = nbs[i]; pl.NTW = ntw[i]; }
+    }
+  }
+  pl.COT = pl.NBC * 16;
+  pl.coTiles = (int)mpa_cdiv(d->Cout, pl.COT);
+  pl.nPerBlock = 4 * pl.NTW * 16;
+  pl.nTiles = (int)mpa_cdiv(pl.Ntot, pl.nPerBlock);
+  pl.XCH = std::min(d->Cin, (pl.nPerBlock + khkw - 2) / khkw + 1);
+  // pixel tile: full-width rows when they fit in LDS, else split the width
+  double bestcost = 1e300;
+  for (int txn = 1; txn <= OW; ++txn) {
+    const int TW = (int)mpa_cdiv(OW, txn);
+    const int DP = (int)mpa_cdiv(TW, 4) * 4;
+    const int IW = (DP - 1) * d->sw + d->kw;
+    const int LW = IW | 1;
+    for (int TH = std::min(OH, 64); TH >= 1; --TH) {
+      const int IH = (TH - 1) * d->sh + d->kh;
+      const int XCHP = IH * LW;
+      const int DCP = round_mod(TH * DP, 32, 2);
+      const size_t lds = (size_t)(pl.XCH * XCHP + pl.COT * DCP) * 4;
+      if (lds > 64 * 1024) continue;
+      const int ty = (int)mpa_cdiv(OH, TH);
+      // MFMA work ~ padded pixels; staging ~ tile bytes
+      double cost = (double)ty * txn * (TH * DP * (double)(pl.NBC * pl.NTW) * 4 * 8 + 0.5 * (lds / 4));
+      if (cost < bestcost) {
+        bestcost = cost;
+        pl.TH = TH; pl.TW = TW; pl.DP = DP; pl.tilesY = ty; pl.tilesX = txn; pl.IH = IH; pl.IW = IW; pl.LW = LW;
+        pl.XCHP = XCHP; pl.DCP = DCP; pl.lds_bytes = lds; pl.ok = true;
+      }
+      break;   // largest TH that fits for this TW
+    }
+    if (txn > 8 && pl.ok) break;
+  }
+  if (!pl.ok) return pl;
+  const long totalTiles = (long)d->B * pl.tilesY * pl.tilesX;
+  long S = (256L * 3) / ((long)pl.nTiles * pl.coTiles);
+  if (S < 1) S = 1;
+  if (S > totalTiles) S = totalTiles;
+  pl.S = (int)S;
+  return pl;
+}
+
+struct WgParams {
+  const float* x;
+  const float* dy;
+  float* ws;
+  int B, Cin, H, W, Cout, OH, OW, kh, kw, sh, sw, ph, pw;
+  int COT, nPerBlock, Ntot, XCH, TH, TW, DP, tilesY, tilesX, IH, IW, LW, XCHP, DCP, S;
+};
+
+template <int NBC, int NTW>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* lds_x = lds;
+  float* lds_dy = lds + p.XCH * p.XCHP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kq = lane >> 4, l16 = lane & 15;
+  const int split = blockIdx.x, ntile = blockIdx.y, cot = blockIdx.z;
+  const int khkw = p.kh * p.kw;
+  const int nblk0 = ntile * p.nPerBlock;
+  const int ci_first = nblk0 / khkw;
+  const int n_base = nblk0 + wave * NTW * 16;
+  int xoff[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    int n = n_base + t * 16 + l16;
+    if (n >= p.Ntot) n = nblk0;
+    const int ci = n / khkw, r = n - ci * khkw;
+    const int dy = r / p.kw, dx = r - dy * p.kw;
+    xoff[t] = (ci - ci_first) * p.XCHP + dy * p.LW + dx + kq * p.sw;
+  }
+  const int aoff = l16 * p.DCP + kq;
+  f32x4 acc[NBC][NTW];
+#pragma unroll
+  for (int i = 0; i < NBC; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int tilesPerImg = p.tilesY * p.tilesX;
+  const long totalTiles = (long)p.B * tilesPerImg;
+  for (long tile = split; tile < totalTiles; tile += p.S) {
+    const int b = (int)(tile / tilesPerImg);
+    const int tr = (int)(tile - (long)b * tilesPerImg);
+    const int ty = tr / p.tilesX, tx = tr - ty * p.tilesX;
+    const int oy0 = ty * p.TH, ox0 = tx * p.TW;
+    const int iy0 = oy0 * p.sh - p.ph, ix0 = ox0 * p.sw - p.pw;
+    __syncthreads();
+    stage_window(lds_x, p.x + (long)b * p.Cin * p.H * p.W, tid, p.XCH, p.IH, p.IW, p.XCHP, p.LW, ci_first, iy0, ix0,
+                 p.Cin, p.H, p.W, p.W);
+    // dY tile: columns >= TW belong to the neighbouring tile -> clip the readable width at ox0+TW
+    stage_window(lds_dy, p.dy + (long)b * p.Cout * p.OH * p.OW, tid, p.COT, p.TH, p.DP, p.DCP, p.DP, cot * p.COT, oy0,
+                 ox0, p.Cout, p.OH, p.OW, min(p.OW, ox0 + p.TW));
+    __syncthreads();
+    for (int py = 0; py < p.TH; ++py) {
+      const float* ap = lds_dy + py * p.DP + aoff;
+      const float* bp = lds_x + py * p.sh * p.LW;
+#pragma unroll 2
+      for (int px0 = 0; px0 < p.DP; px0 += 4) {
+        float a[NBC], bv[NTW];
+#pragma unroll
+        for (int cb = 0; cb < NBC; ++cb) a[cb] = ap[cb * 16 * p.DCP + px0];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) bv[t] = bp[xoff[t] + px0 * p.sw];
+#pragma unroll
+        for (int cb = 0; cb < NBC; ++cb)
+#pragma unroll
+          for (int t = 0; t < NTW; ++t)
+            acc[cb][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb], bv[t], acc[cb][t], 0, 0, 0);
+      }
+    }
+  }
+  // partial slice -> workspace [split][Cout][Ntot]
+  float* out = p.ws + (long)split * p.Cout * p.Ntot;
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const int n = n_base + t * 16 + l16;
+    if (n >= p.Ntot) continue;
+#pragma unroll
+    for (int cb = 0; cb < NBC; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = cot * p.COT + cb * 16 + kq * 4 + r;
+        if (co < p.Cout) out[(long)co * p.Ntot + n] = acc[cb][t][r];
+      }
+  }
+}
+
+__global__ void reduce_partials_kernel(const float* ws, float* out, long n, int S) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += ws[(long)k * n + i];
+    out[i] = s;
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+int64_t mpa_conv2d_packed_floats(const mpa_conv_desc* d, int mode) {
+  if (!d) return MPA_ERR_ARG;
+  FwdPlan pl;
+  if (mode == 0) {
+    pl = plan_fwd(d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw);
+  } else {
+    BwdDataGeom g = bwd_data_geom(d);
+    if (!g.ok) return MPA_ERR_UNSUPPORTED;
+    pl = plan_fwd(g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw);
+  }
+  if (!pl.ok) return MPA_ERR_UNSUPPORTED;
+  const int kh = d->kh, kw = (mode == 1 && bwd_data_geom(d).xphase) ? 1 : d->kw;
+  return (int64_t)pl.coTiles * pl.nChunks * kh * kw * pl.CK * pl.COTP;
+}
+
+int mpa_conv2d_pack(const mpa_conv_desc* d, int mode, const float* w, float* w_packed, void* stream) {
+  if (!d || !w || !w_packed) return MPA_ERR_ARG;
+  PackParams p{};
+  p.w = w; p.wp = w_packed;
+  p.Cout_w = d->Cout; p.Cin_w = d->Cin; p.kh_w = d->kh; p.kw_w = d->kw;
+  p.mode = mode; p.xphase = 0;
+  FwdPlan pl;
+  if (mode == 0) {
+    pl = plan_fwd(d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw);
+    p.CinP = d->Cin; p.CoutP = d->Cout; p.kh = d->kh; p.kw = d->kw;
+  } else {
+    BwdDataGeom g = bwd_data_geom(d);
+    if (!g.ok) return MPA_ERR_UNSUPPORTED;
+    pl = plan_fwd(g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw);
+    p.CinP = g.Cin; p.CoutP = g.Cout; p.kh = g.kh; p.kw = g.kw; p.xphase = g.xphase ? 1 : 0;
+  }
+  if (!pl.ok) return MPA_ERR_UNSUPPORTED;
+  p.CK = pl.CK; p.nChunks = pl.nChunks; p.COT = pl.COT; p.COTP = pl.COTP; p.coTiles = pl.coTiles;
+  p.total = (long)pl.coTiles * pl.nChunks * p.kh * p.kw * pl.CK * pl.COTP;
+  const int blocks = (int)std::min<long>(mpa_cdiv(p.total, 256), 4096);
+  hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  return mpa_launch_status();
+}
+
+static int conv_fwd_impl(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                         const float* x, const float* wp, const float* bias, float* y, int act, float slope,
+                         long outBS, long outCS, int outRS, int outXmul, int outCdiv, hipStream_t s) {
+  FwdPlan pl = plan_fwd(Cin, H, W, Cout, kh, kw, sh, sw, ph, pw);
+  if (!pl.ok) return MPA_ERR_UNSUPPORTED;
+  ConvFwdParams p{};
+  p.x = x; p.wp = wp; p.bias = bias; p.y = y;
+  p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.OH = pl.OH; p.OW = pl.OW;
+  p.kh = kh; p.kw = kw; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw;
+  p.TH = pl.TH; p.TW = pl.TW; p.tilesY = pl.tilesY; p.tilesX = pl.tilesX; p.CK = pl.CK; p.nChunks = pl.nChunks;
+  p.IH = pl.IH; p.IW = pl.IW; p.LW = pl.LW; p.CHP = pl.CHP; p.COT = pl.COT; p.COTP = pl.COTP;
+  p.act = act; p.slope = slope;
+  p.outBS = outBS; p.outCS = outCS; p.outRS = outRS; p.outXmul = outXmul; p.outCdiv = outCdiv;
+  return launch_fwd(pl, p, s);
+}
+
+int mpa_conv2d_fwd(const mpa_conv_desc* d, const float* x, const float* w_packed, const float* bias, float* y,
+                   int act, float slope, void* stream) {
+  if (!d || !x || !w_packed || !y || d->B <= 0) return MPA_ERR_ARG;
+  const int OH = (d->H + 2 * d->ph - d->kh) / d->sh + 1, OW = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
+  if (OH <= 0 || OW <= 0) return MPA_ERR_ARG;
+  return conv_fwd_impl(d->B, d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw, x, w_packed, bias,
+                       y, act, slope, (long)d->Cout * OH * OW, (long)OH * OW, OW, 1, d->Cout, (hipStream_t)stream);
+}
+
+int mpa_conv2d_bwd_data(const mpa_conv_desc* d, const float* dy, const float* w_packed, float* dx, void* stream) {
+  if (!d || !dy || !w_packed || !dx || d->B <= 0) return MPA_ERR_ARG;
+  BwdDataGeom g = bwd_data_geom(d);
+  if (!g.ok) return MPA_ERR_UNSUPPORTED;
+  const long inBS = (long)d->Cin * d->H * d->W, inCS = (long)d->H * d->W;
+  if (!g.xphase) {
+    // output of the derived conv has size H x W again
+    return conv_fwd_impl(d->B, g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw, dy, w_packed, nullptr, dx,
+                         MPA_ACT_NONE, 0.f, inBS, inCS, d->W, 1, g.Cout, (hipStream_t)stream);
+  }
+  return conv_fwd_impl(d->B, g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw, dy, w_packed, nullptr, dx,
+                       MPA_ACT_NONE, 0.f, inBS, inCS, d->W, d->sw, d->Cin, (hipStream_t)stream);
+}
+
+int64_t mpa_conv2d_bwd_weight_workspace(const mpa_conv_desc* d) {
+  if (!d) return MPA_ERR_ARG;
+  WgPlan pl = plan_wgrad(d);
+  if (!pl.ok) return MPA_ERR_UNSUPPORTED;
+  return (int64_t)pl.S * d->Cout * pl.Ntot * 4;
+}
+
+int mpa_channel_sum(const float* x, float* out, int B, int C, int HW, void* stream);
+
+int mpa_conv2d_bwd_weight(const mpa_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
+                          void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!d || !x || !dy || !dw || d->B <= 0) return MPA_ERR_ARG;
+  WgPlan pl = plan_wgrad(d);
+  if (!pl.ok) return MPA_ERR_UNSUPPORTED;
+  const int64_t need = (int64_t)pl.S * d->Cout * pl.Ntot * 4;
+  if (!workspace || workspace_bytes < need) return MPA_ERR_WORKSPACE;
+  WgParams p{};
+  p.x = x; p.dy = dy; p.ws = (float*)workspace;
+  p.B = d->B; p.Cin = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout; p.OH = pl.OH; p.OW = pl.OW;
+  p.kh = d->kh; p.kw = d->kw; p.sh = d->sh; p.sw = d->sw; p.ph = d->ph; p.pw = d->pw;
+  p.COT = pl.COT; p.nPerBlock = pl.nPerBlock; p.Ntot = pl.Ntot; p.XCH = pl.XCH; p.TH = pl.TH; p.TW = pl.TW; p.DP = pl.DP;
+  p.tilesY = pl.tilesY; p.tilesX = pl.tilesX; p.IH = pl.IH; p.IW = pl.IW; p.LW = pl.LW; p.XCHP = pl.XCHP; p.DCP = pl.DCP;
+  p.S = pl.S;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)pl.S, (unsigned)pl.nTiles, (unsigned)pl.coTiles);
+  if (pl.NBC == 1) hipLaunchKernelGGL((conv_wgrad_kernel<1, 16>), grid, dim3(256), pl.lds_bytes, s, p);
+  else if (pl.NBC == 2) hipLaunchKernelGGL((conv_wgrad_kernel<2, 8>), grid, dim3(256), pl.lds_bytes, s, p);
+  else if (pl.NBC == 4) hipLaunchKernelGGL((conv_wgrad_kernel<4, 6>), grid, dim3(256), pl.lds_bytes, s, p);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<5, 6>), grid, dim3(256), pl.lds_bytes, s, p);
+  int rc = mpa_launch_status();
+  if (rc) return rc;
+  const long n = (long)d->Cout * pl.Ntot;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)std::min<long>(mpa_cdiv(n, 256), 2048)), dim3(256), 0, s,
+                     (const float*)workspace, dw, n, pl.S);
+  rc = mpa_launch_status();
+  if (rc) return rc;
+  if (db) return mpa_channel_sum(dy, db, d->B, d->Cout, pl.OH * pl.OW, stream);
+  return MPA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,41 @@
+// Shared helpers for the gfx950 kernels of libmpa_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mpa.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MPA_WAVE 64
+
+static inline int mpa_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MPA_OK : MPA_ERR_LAUNCH;
+}
+
+static inline int64_t mpa_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float mpa_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double mpa_wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float mpa_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float mpa_apply_act(float v, int act, float slope) {
+  switch (act) {
+    case MPA_ACT_RELU: return v > 0.f ? v : 0.f;
+    case MPA_ACT_LRELU: return v >= 0.f ? v : v * slope;
+    case MPA_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+    default: return v;
+  }
+}

@@ -1,0 +1,398 @@
+// Pointwise / small-reduction kernels: activations, dropout, adds, transposes, channel sums, losses,
+// LSTM cell, AdamW.  All HBM-bound; float4 where alignment allows.
+#include "mpa_common.h"
+#include <algorithm>
+
+namespace {
+
+inline unsigned blocks_for(long n, int per = 256) {
+  return (unsigned)std::max<long>(1, std::min<long>(mpa_cdiv(n, per), 1 << 16));
+}
+
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n, int act,
+                                                      float slope) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float v = x[i];
+    float r;
+    if (act == MPA_ACT_SIGMOID) r = 1.f / (1.f + expf(-v));
+    else r = mpa_apply_act(v, act, slope);
+    y[i] = r;
+  }
+}
+
+// dx = dy * act'(x); for sigmoid `x` must be the *output* y
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                      float* __restrict__ dx, long n, int act, float slope) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float v = x[i], g = dy[i];
+    float r;
+    switch (act) {
+      case MPA_ACT_RELU: r = v > 0.f ? g : 0.f; break;
+      case MPA_ACT_LRELU: r = v >= 0.f ? g : g * slope; break;
+      case MPA_ACT_SIGMOID: r = g * v * (1.f - v); break;
+      default: r = g;
+    }
+    dx[i] = r;
+  }
+}
+
+// counter-based RNG (splitmix64 finaliser over seed/offset/index); keep iff u >= p, scale 1/(1-p)
+__device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float p,
+                                                      float scale, uint64_t seed, uint64_t offset) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float u = rng_uniform(seed, offset + (uint64_t)i);
+    y[i] = u >= p ? x[i] * scale : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = a[i] + b[i];
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(float alpha, const float* __restrict__ x, float* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] += alpha * x[i];
+}
+
+__global__ __launch_bounds__(256) void scale_by_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                       float* __restrict__ y, long n) {
+  const float a = g[0];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = a * x[i];
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(float alpha, float* __restrict__ x, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] *= alpha;
+}
+
+// y[b][c][r] = x[b][r][c] (+ pe)   x: (B,R,Cc) -> y: (B,Cc,R); LDS 32x33 tile transpose.
+// pe_mode 0: none; 1: pe indexed like the OUTPUT's (row=c? no) -- see host wrapper.
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ x, const float* __restrict__ pe,
+                                                        float* __restrict__ y, int R, int Cc, int pe_mode) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const float* xb = x + (long)b * R * Cc;
+  float* yb = y + (long)b * R * Cc;
+  for (int k = ty; k < 32; k += 8) {
+    const int r = r0 + k, c = c0 + tx;
+    float v = 0.f;
+    if (r < R && c < Cc) {
+      v = xb[(long)r * Cc + c];
+      if (pe_mode == 2) v += pe[(long)r * Cc + c];      // pe laid out like the input (R,Cc)
+    }
+    tile[k][tx] = v;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k, r = r0 + tx;
+    if (r < R && c < Cc) {
+      float v = tile[tx][k];
+      if (pe_mode == 1) v += pe[(long)c * R + r];       // pe laid out like the output (Cc,R)
+      yb[(long)c * R + r] = v;
+    }
+  }
+}
+
+// out[c] = sum_{b,i} x[b][c][i]   grid (C): one block per channel (bias gradients; small C, long rows)
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int C,
+                                                          int HW) {
+  const int c = blockIdx.x;
+  const long per = (long)B * HW;
+  double acc = 0.0;
+  float s = 0.f;
+  int cnt = 0;
+  for (long i = threadIdx.x; i < per; i += 256) {
+    const int b = (int)(i / HW);
+    const int r = (int)(i - (long)b * HW);
+    s += x[((long)b * C + c) * HW + r];
+    if (++cnt == 64) { acc += s; s = 0.f; cnt = 0; }
+  }
+  acc += s;
+  acc = mpa_wave_sum_d(acc);
+  __shared__ double sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[c] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+// out[n] (+)= sum_rows x[row][n]; grid (ceil(N/64)); block 256 = 4 row-groups x 64 columns
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long rows, int N,
+                                                     int accumulate) {
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int g = threadIdx.x >> 6;
+  float s = 0.f;
+  if (col < N)
+    for (long r = g; r < rows; r += 4) s += x[r * N + col];
+  __shared__ float sh[4][64];
+  sh[g][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (g == 0 && col < N) {
+    const float t = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+    out[col] = accumulate ? out[col] + t : t;
+  }
+}
+
+__global__ __launch_bounds__(256) void add_rows_bcast_kernel(const float* __restrict__ x, const float* __restrict__ pe,
+                                                             float* __restrict__ y, long n, long SE) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = x[i] + pe[i % SE];
+}
+
+// ------------------------------------------------------------------ losses
+__global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ p, const float* __restrict__ y,
+                                                      float* __restrict__ loss, long n, float inv_n) {
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float pi = p[i], yi = y[i];
+    const float lp = fmaxf(logf(pi), -100.f), lq = fmaxf(logf(1.f - pi), -100.f);
+    s -= yi * lp + (1.f - yi) * lq;
+  }
+  s = mpa_wave_sum(s);
+  __shared__ float sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (sh[0] + sh[1] + sh[2] + sh[3]) * inv_n);
+}
+
+// d/dp of mean BCE as ATen's binary_cross_entropy_backward: (p - y) / max((1-p)*p, 1e-12) * g / n
+__global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ p, const float* __restrict__ y,
+                                                      float* __restrict__ dp, long n, const float* __restrict__ g,
+                                                      float inv_n) {
+  const float gscale = (g ? g[0] : 1.f) * inv_n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float pi = p[i];
+    dp[i] = (pi - y[i]) / fmaxf((1.f - pi) * pi, 1e-12f) * gscale;
+  }
+}
+
+// one wave per row; loss += scale * mean(lse - logit[target]); dlogits = scale/B * (softmax - onehot)
+__global__ __launch_bounds__(64) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                float* __restrict__ loss, float* __restrict__ dlogits, int B, int K,
+                                                float scale) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float* row = logits + (long)b * K;
+  float m = -INFINITY;
+  for (int k = lane; k < K; k += 64) m = fmaxf(m, row[k]);
+  m = mpa_wave_max(m);
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s += expf(row[k] - m);
+  s = mpa_wave_sum(s);
+  const float lse = m + logf(s);
+  const int t = (int)target[b];
+  const float w = scale / (float)B;
+  if (dlogits)
+    for (int k = lane; k < K; k += 64) dlogits[(long)b * K + k] = w * (expf(row[k] - lse) - (k == t ? 1.f : 0.f));
+  if (lane == 0) atomicAdd(loss, w * (lse - row[t]));
+}
+
+// ------------------------------------------------------------------ LSTM cell
+// acts (B,4H) receives sigmoid(i), sigmoid(f), tanh(g), sigmoid(o)
+__global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(const float* __restrict__ gates, long g_stride,
+                                                            const float* __restrict__ c_prev, float* __restrict__ c,
+                                                            float* __restrict__ h, long h_stride, float* __restrict__ acts,
+                                                            int B, int H) {
+  const long n = (long)B * H;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int b = (int)(i / H), j = (int)(i - (long)b * H);
+    const float* g = gates + (long)b * g_stride;
+    const float ig = 1.f / (1.f + expf(-g[j]));
+    const float fg = 1.f / (1.f + expf(-g[H + j]));
+    const float gg = tanhf(g[2 * H + j]);
+    const float og = 1.f / (1.f + expf(-g[3 * H + j]));
+    const float cp = c_prev ? c_prev[i] : 0.f;
+    const float cn = fg * cp + ig * gg;
+    c[i] = cn;
+    h[(long)b * h_stride + j] = og * tanhf(cn);
+    float* a = acts + (long)b * 4 * H;
+    a[j] = ig; a[H + j] = fg; a[2 * H + j] = gg; a[3 * H + j] = og;
+  }
+}
+
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restrict__ dh, long dh_stride,
+                                                            const float* __restrict__ dh_rec,
+                                                            const float* __restrict__ dc_next, const float* __restrict__ acts,
+                                                            const float* __restrict__ c_prev, const float* __restrict__ c,
+                                                            float* __restrict__ dgates, long dg_stride,
+                                                            float* __restrict__ dc_prev, int B, int H) {
+  const long n = (long)B * H;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int b = (int)(i / H), j = (int)(i - (long)b * H);
+    const float* a = acts + (long)b * 4 * H;
+    const float ig = a[j], fg = a[H + j], gg = a[2 * H + j], og = a[3 * H + j];
+    const float tc = tanhf(c[i]);
+    const float dht = dh[(long)b * dh_stride + j] + (dh_rec ? dh_rec[i] : 0.f);
+    float dct = dht * og * (1.f - tc * tc) + (dc_next ? dc_next[i] : 0.f);
+    const float cp = c_prev ? c_prev[i] : 0.f;
+    float* dg = dgates + (long)b * dg_stride;
+    dg[j] = dct * gg * ig * (1.f - ig);
+    dg[H + j] = dct * cp * fg * (1.f - fg);
+    dg[2 * H + j] = dct * ig * (1.f - gg * gg);
+    dg[3 * H + j] = dht * tc * og * (1.f - og);
+    dc_prev[i] = dct * fg;
+  }
+}
+
+// ------------------------------------------------------------------ AdamW (multi-tensor)
+__global__ __launch_bounds__(256) void adamw_kernel(float* const* __restrict__ params, const float* const* __restrict__ grads,
+                                                    float* const* __restrict__ m_, float* const* __restrict__ v_,
+                                                    const int64_t* __restrict__ sizes, float lr, float b1, float b2,
+                                                    float eps, float wd, float bc1, float bc2_sqrt) {
+  const int t = blockIdx.y;
+  const long n = sizes[t];
+  float* p = params[t];
+  const float* g = grads[t];
+  float* m = m_[t];
+  float* v = v_[t];
+  if (!g) return;
+  const float step_size = lr / bc1;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float gi = g[i];
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= step_size * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mpa_strerror(int code) {
+  switch (code) {
+    case MPA_OK: return "ok";
+    case MPA_ERR_ARG: return "invalid argument";
+    case MPA_ERR_LAUNCH: return "kernel launch failed";
+    case MPA_ERR_UNSUPPORTED: return "unsupported configuration";
+    case MPA_ERR_WORKSPACE: return "workspace too small";
+    default: return "unknown error";
+  }
+}
+int mpa_version(void) { return 1; }
+
+int mpa_act_fwd(const float* x, float* y, int64_t n, int act, float slope, void* stream) {
+  if (!x || !y) return MPA_ERR_ARG;
+  if (n == 0) return MPA_OK;
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, (long)n, act, slope);
+  return mpa_launch_status();
+}
+int mpa_act_bwd(const float* dy, const float* x, float* dx, int64_t n, int act, float slope, void* stream) {
+  if (!dy || !x || !dx) return MPA_ERR_ARG;
+  if (n == 0) return MPA_OK;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, dy, x, dx, (long)n, act, slope);
+  return mpa_launch_status();
+}
+int mpa_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream) {
+  if (!x || !y || p < 0.f || p >= 1.f) return MPA_ERR_ARG;
+  if (n == 0) return MPA_OK;
+  hipLaunchKernelGGL(dropout_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, (long)n, p, 1.f / (1.f - p),
+                     seed, offset);
+  return mpa_launch_status();
+}
+int mpa_add(const float* a, const float* b, float* y, int64_t n, void* stream) {
+  if (!a || !b || !y) return MPA_ERR_ARG;
+  if (n == 0) return MPA_OK;
+  hipLaunchKernelGGL(add_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, (long)n);
+  return mpa_launch_status();
+}
+int mpa_axpy(float alpha, const float* x, float* y, int64_t n, void* stream) {
+  if (!x || !y) return MPA_ERR_ARG;
+  if (n == 0) return MPA_OK;
+  hipLaunchKernelGGL(axpy_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, alpha, x, y, (long)n);
+  return mpa_launch_status();
+}
+int mpa_scale_by(const float* x, const float* g, float* y, int64_t n, void* stream) {
+  if (!x || !g || !y) return MPA_ERR_ARG;
+  if (n == 0) return MPA_OK;
+  hipLaunchKernelGGL(scale_by_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, g, y, (long)n);
+  return mpa_launch_status();
+}
+int mpa_scale(float alpha, float* x, int64_t n, void* stream) {
+  if (!x) return MPA_ERR_ARG;
+  if (n == 0) return MPA_OK;
+  hipLaunchKernelGGL(scale_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, alpha, x, (long)n);
+  return mpa_launch_status();
+}
+// x (B,R,Cc) -> y (B,Cc,R); pe_mode 0 none, 1 add pe (Cc,R) to the output, 2 add pe (R,Cc) to the input
+int mpa_transpose_add(const float* x, const float* pe, float* y, int B, int R, int Cc, int pe_mode, void* stream) {
+  if (!x || !y || (pe_mode && !pe)) return MPA_ERR_ARG;
+  dim3 grid((unsigned)mpa_cdiv(Cc, 32), (unsigned)mpa_cdiv(R, 32), (unsigned)B);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, pe, y, R, Cc, pe_mode);
+  return mpa_launch_status();
+}
+int mpa_channel_sum(const float* x, float* out, int B, int C, int HW, void* stream) {
+  if (!x || !out) return MPA_ERR_ARG;
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, out, B, C, HW);
+  return mpa_launch_status();
+}
+int mpa_colsum(const float* x, float* out, int64_t rows, int N, int accumulate, void* stream) {
+  if (!x || !out) return MPA_ERR_ARG;
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)mpa_cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, x, out, (long)rows, N,
+                     accumulate);
+  return mpa_launch_status();
+}
+int mpa_add_rows_bcast(const float* x, const float* pe, float* y, int B, int64_t SE, void* stream) {
+  if (!x || !pe || !y) return MPA_ERR_ARG;
+  const long n = (long)B * SE;
+  hipLaunchKernelGGL(add_rows_bcast_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, pe, y, n, (long)SE);
+  return mpa_launch_status();
+}
+
+int mpa_bce_fwd(const float* p, const float* y, float* loss_out, int64_t n, void* stream) {
+  if (!p || !y || !loss_out || n <= 0) return MPA_ERR_ARG;
+  hipLaunchKernelGGL(bce_fwd_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, y, loss_out, (long)n,
+                     1.0f / (float)n);
+  return mpa_launch_status();
+}
+int mpa_bce_bwd(const float* p, const float* y, float* dp, int64_t n, const float* g, void* stream) {
+  if (!p || !y || !dp || n <= 0) return MPA_ERR_ARG;
+  hipLaunchKernelGGL(bce_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, p, y, dp, (long)n, g,
+                     1.0f / (float)n);
+  return mpa_launch_status();
+}
+int mpa_ce_fwd_bwd(const float* logits, const int64_t* target, float* loss_out, float* dlogits, int B, int K, float scale,
+                   void* stream) {
+  if (!logits || !target || !loss_out || B <= 0) return MPA_ERR_ARG;
+  hipLaunchKernelGGL(ce_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, logits, target, loss_out, dlogits, B, K, scale);
+  return mpa_launch_status();
+}
+
+int mpa_lstm_cell_fwd(const float* gates, int64_t g_stride, const float* c_prev, float* c, float* h, int64_t h_stride,
+                      float* acts, int B, int H, void* stream) {
+  if (!gates || !c || !h || !acts) return MPA_ERR_ARG;
+  hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(blocks_for((long)B * H)), dim3(256), 0, (hipStream_t)stream, gates,
+                     (long)g_stride, c_prev, c, h, (long)h_stride, acts, B, H);
+  return mpa_launch_status();
+}
+int mpa_lstm_cell_bwd(const float* dh, int64_t dh_stride, const float* dh_rec, const float* dc_next, const float* acts,
+                      const float* c_prev, const float* c, float* dgates, int64_t dg_stride, float* dc_prev, int B, int H,
+                      void* stream) {
+  if (!dh || !acts || !c || !dgates || !dc_prev) return MPA_ERR_ARG;
+  hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(blocks_for((long)B * H)), dim3(256), 0, (hipStream_t)stream, dh,
+                     (long)dh_stride, dh_rec, dc_next, acts, c_prev, c, dgates, (long)dg_stride, dc_prev, B, H);
+  return mpa_launch_status();
+}
+
+int mpa_adamw_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                   const int64_t* sizes, int ntensors, int64_t max_size, double lr, double beta1, double beta2, double eps,
+                   double weight_decay, int step, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !sizes || ntensors <= 0 || step <= 0) return MPA_ERR_ARG;
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  dim3 grid((unsigned)std::max<long>(1, std::min<long>(mpa_cdiv(max_size, 1024), 512)), (unsigned)ntensors);
+  hipLaunchKernelGGL(adamw_kernel, grid, dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, sizes, (float)lr,
+                     (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)bc1, (float)sqrt(bc2));
+  return mpa_launch_status();
+}
+
+}  // extern "C"

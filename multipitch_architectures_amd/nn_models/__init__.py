@@ -1,0 +1,40 @@
+"""Drop-in for ``libdl.nn_models`` (the reference's import surface, libdl/nn_models/__init__.py:1-10).
+
+The 7 model classes every experiment script instantiates and the 4 building
+blocks they are made of run on hand-written gfx950 kernels.  The remaining
+exported names of the reference (variants no experiment uses, two of which
+cannot even be constructed upstream -- SURVEY.md Appendix C.7) are kept
+importable and raise ``NotImplementedError`` on construction.
+"""
+from .basic_cnns import basic_cnn_segm_sigmoid, deep_cnn_segm_sigmoid
+from .unet_cnns import (blstm_temporal_enc_layer, double_conv, simple_u_net_doubleselfattn,
+                        simple_u_net_doubleselfattn_twolayers, simple_u_net_largekernels,
+                        simple_u_net_polyphony_classif_softmax, transformer_enc_layer, u_net_blstm_varlayers,
+                        unet_up_concat_padding)
+
+BUILT = ["basic_cnn_segm_sigmoid", "deep_cnn_segm_sigmoid", "double_conv", "unet_up_concat_padding",
+         "transformer_enc_layer", "blstm_temporal_enc_layer", "simple_u_net_largekernels",
+         "simple_u_net_doubleselfattn", "simple_u_net_doubleselfattn_twolayers", "u_net_blstm_varlayers",
+         "simple_u_net_polyphony_classif_softmax"]
+
+NOT_BUILT = ["basic_cnn", "basic_cnn_pool", "basic_cnn_segm_logsoftmax", "basic_cnn_segm_blank_logsoftmax",
+             "single_conv", "simple_u_net", "simple_u_net_selfattn", "freq_u_net", "freq_u_net_bottomstack",
+             "freq_u_net_selfattn", "freq_u_net_doubleselfattn", "simple_u_net_doubleselfattn_alllayers",
+             "simple_u_net_doubleselfattn_varlayers", "simple_u_net_sixselfattn", "u_net_temporal_selfattn_varlayers",
+             "transformer_temporal_enc_layer", "simple_u_net_doubleselfattn_transenc", "u_net_temporal_blstm_varlayers",
+             "simple_u_net_doubleselfattn_polyphony", "simple_u_net_doubleselfattn_polyphony_classif",
+             "simple_u_net_polyphony_classif"]
+
+
+def _not_built(name):
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError(
+            f"libdl.nn_models.{name} is exported by the reference but used by none of its experiment scripts; "
+            "it is not part of the MI355X hot path yet (see DESIGN.md, 'out of scope')")
+    return type(name, (object,), {"__init__": __init__, "__doc__": f"placeholder for the reference's unused {name}"})
+
+
+for _n in NOT_BUILT:
+    globals()[_n] = _not_built(_n)
+
+__all__ = BUILT + NOT_BUILT

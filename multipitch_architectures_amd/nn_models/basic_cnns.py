@@ -1,0 +1,91 @@
+"""CNN / DCNN / DRCNN families -- drop-in for libdl/nn_models/basic_cnns.py.
+
+Constructor signatures, defaults, attribute names and ``state_dict`` keys follow
+the reference (basic_cnns.py:152, :363); the arithmetic runs in HIP kernels via
+multipitch_architectures_amd.ops.
+"""
+import torch.nn as nn
+
+from .layers import (Conv2d, ConvActPoolDrop, Dropout, LayerNorm, LeakyReLU, MaxPool2d, OutputHead, Sigmoid)
+from .. import ops
+
+
+def _head(n_ch_prev, n_ch, n_bins_in, n_bins_out, a_lrelu, p_dropout):
+    """conv2 (binning to MIDI pitches), conv3 (time reduction), conv4 (chroma reduction): basic_cnns.py:389-408."""
+    last_kernel_size = n_bins_in // 3 + 1 - n_bins_out
+    conv2 = ConvActPoolDrop(
+        Conv2d(n_ch_prev, n_ch[1], kernel_size=(3, 3), padding=(1, 0), stride=(1, 3)),
+        LeakyReLU(negative_slope=a_lrelu),
+        MaxPool2d(kernel_size=(13, 1), stride=(1, 1), padding=(6, 0)),
+        Dropout(p=p_dropout))
+    conv3 = ConvActPoolDrop(
+        Conv2d(n_ch[1], n_ch[2], kernel_size=(75, 1), padding=(0, 0), stride=(1, 1)),
+        LeakyReLU(negative_slope=a_lrelu),
+        Dropout(p=p_dropout))
+    conv4 = OutputHead(
+        Conv2d(n_ch[2], n_ch[3], kernel_size=(1, 1), padding=(0, 0), stride=(1, 1)),
+        LeakyReLU(negative_slope=a_lrelu),
+        Dropout(p=p_dropout),
+        Conv2d(n_ch[3], 1, kernel_size=(1, last_kernel_size), padding=(0, 0), stride=(1, 1)),
+        Sigmoid())
+    return conv2, conv3, conv4
+
+
+def _prefilter(n_in, n_out, a_lrelu, p_dropout):
+    return ConvActPoolDrop(
+        Conv2d(n_in, n_out, kernel_size=(15, 15), padding=(7, 7), stride=(1, 1)),
+        LeakyReLU(negative_slope=a_lrelu),
+        MaxPool2d(kernel_size=(3, 1), stride=(1, 1), padding=(1, 0)),
+        Dropout(p=p_dropout))
+
+
+class basic_cnn_segm_sigmoid(nn.Module):
+    """basic_cnns.py:133-195 -- HCQT (B,6,T>=75,216) -> (B,1,T-74,n_bins_out) pitch activations."""
+
+    def __init__(self, n_chan_input=6, n_chan_layers=[20, 20, 10, 1], n_bins_in=216, n_bins_out=12, a_lrelu=0.3,
+                 p_dropout=0.2):
+        super().__init__()
+        n_in, n_ch = n_chan_input, n_chan_layers
+        self.layernorm = LayerNorm(normalized_shape=[n_in, n_bins_in])
+        self.conv1 = _prefilter(n_in, n_ch[0], a_lrelu, p_dropout)
+        self.conv2, self.conv3, self.conv4 = _head(n_ch[0], n_ch, n_bins_in, n_bins_out, a_lrelu, p_dropout)
+
+    def forward(self, x):
+        x_norm = self.layernorm.forward_cf(x)
+        conv1_lrelu = self.conv1(x_norm)
+        conv2_lrelu = self.conv2(conv1_lrelu)
+        conv3_lrelu = self.conv3(conv2_lrelu)
+        y_pred = self.conv4(conv3_lrelu)
+        return y_pred
+
+
+class deep_cnn_segm_sigmoid(nn.Module):
+    """basic_cnns.py:342-423 -- n_prefilt_layers 15x15 prefilter blocks, optional residual adds."""
+
+    def __init__(self, n_chan_input=6, n_chan_layers=[20, 20, 10, 1], n_prefilt_layers=1, residual=False, n_bins_in=216,
+                 n_bins_out=12, a_lrelu=0.3, p_dropout=0.2):
+        super().__init__()
+        n_in, n_ch = n_chan_input, n_chan_layers
+        self.layernorm = LayerNorm(normalized_shape=[n_in, n_bins_in])
+        self.conv1 = _prefilter(n_in, n_ch[0], a_lrelu, p_dropout)
+        self.n_prefilt_layers = n_prefilt_layers
+        self.prefilt_list = nn.ModuleList()
+        for p in range(1, n_prefilt_layers):
+            self.prefilt_list.append(_prefilter(n_ch[0], n_ch[0], a_lrelu, p_dropout))
+        self.residual = residual
+        self.conv2, self.conv3, self.conv4 = _head(n_ch[0], n_ch, n_bins_in, n_bins_out, a_lrelu, p_dropout)
+
+    def forward(self, x):
+        x_norm = self.layernorm.forward_cf(x)
+        x = self.conv1(x_norm)
+        for p in range(0, self.n_prefilt_layers - 1):
+            prefilt_layer = self.prefilt_list[p]
+            if self.residual:
+                x_new = prefilt_layer(x)
+                x = ops.add(x_new, x)
+            else:
+                x = prefilt_layer(x)
+        conv2_lrelu = self.conv2(x)
+        conv3_lrelu = self.conv3(conv2_lrelu)
+        y_pred = self.conv4(conv3_lrelu)
+        return y_pred

@@ -1,0 +1,344 @@
+"""U-Net family -- drop-in for the classes of libdl/nn_models/unet_cnns.py that the experiments use.
+
+Constructor signatures, defaults, attribute names and ``state_dict`` keys follow
+the reference (file:line cited per class); the arithmetic runs in HIP kernels
+via multipitch_architectures_amd.ops.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .basic_cnns import _head
+from .layers import (BatchNorm2d, Conv2d, ConvActPoolDrop, Dropout, LayerNorm, LeakyReLU, Linear, LSTM, MaxPool2d,
+                     MultiheadAttention, ReLU)
+
+
+class _DoubleConvSeq(nn.Sequential):
+    """Conv -> BN -> ReLU -> Dropout, twice; BN+ReLU run as one fused kernel."""
+
+    def forward(self, x):
+        mods = list(self)
+        h = x
+        i = 0
+        while i < len(mods):
+            conv, bn = mods[i], mods[i + 1]
+            h = bn(conv(h), relu=True)
+            i += 3
+            if i < len(mods) and isinstance(mods[i], Dropout):
+                h = mods[i](h)
+                i += 1
+        return h
+
+
+class double_conv(nn.Module):
+    """ Two convolutional layers, each followed by batch normalization and ReLU  (unet_cnns.py:30-82)"""
+
+    def __init__(self, in_channels, out_channels, mid_channels=None, kernel_size=(3, 3),
+                 padding=(1, 1), convdrop=0, residual=False, alt_order=False):
+        super().__init__()
+        self.residual = residual
+        self.out_channels = out_channels
+        if not mid_channels:
+            mid_channels = out_channels
+        if alt_order:
+            raise NotImplementedError("double_conv(alt_order=True) (ELU-BN-Dropout-Conv, unet_cnns.py:60-70) is not used "
+                                      "by any experiment and is not built yet")
+        if convdrop is None:      # unet_cnns.py:40-48: no Dropout slots -> Sequential indices 0,1,3,4
+            self.double_conv = _DoubleConvSeq(
+                Conv2d(in_channels, mid_channels, kernel_size=kernel_size, padding=padding),
+                BatchNorm2d(mid_channels), ReLU(inplace=True),
+                Conv2d(mid_channels, out_channels, kernel_size=kernel_size, padding=padding),
+                BatchNorm2d(out_channels), ReLU(inplace=True))
+        else:                     # unet_cnns.py:49-59 (default convdrop=0): indices 0,1,4,5
+            self.double_conv = _DoubleConvSeq(
+                Conv2d(in_channels, mid_channels, kernel_size=kernel_size, padding=padding),
+                BatchNorm2d(mid_channels), ReLU(inplace=True), Dropout(p=convdrop),
+                Conv2d(mid_channels, out_channels, kernel_size=kernel_size, padding=padding),
+                BatchNorm2d(out_channels), ReLU(inplace=True), Dropout(p=convdrop))
+        if residual:
+            self.resize = Conv2d(in_channels, out_channels, kernel_size=(1, 1), padding=(0, 0))
+
+    def forward(self, x):
+        x_conv = self.double_conv(x)
+        if self.residual:
+            x_resized = self.resize(x)
+            x_out = ops.add(x_resized, x_conv)
+        else:
+            x_out = x_conv
+        return x_out
+
+
+class unet_up_concat_padding(nn.Module):
+    """ 2-dimensional upsampling and concatenation with fixing padding issues (unet_cnns.py:85-104)"""
+
+    def __init__(self, upsamp_fac=(2, 2), bilinear=True):
+        super().__init__()
+        if tuple(upsamp_fac) != (2, 2):
+            raise NotImplementedError("only the (2,2) bilinear upsampling the reference's models use is built")
+        self.upsamp_fac = tuple(upsamp_fac)
+
+    def forward(self, x1, x2):
+        return ops.upconcat(x1, x2)
+
+
+def _sinusoidal_pe(max_len, embed_dim):
+    """unet_cnns.py:118-124 (built on the CPU; moved to the input's device on first use)."""
+    position = torch.arange(max_len).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, embed_dim, 2) * (-torch.log(torch.tensor(10000.0)) / embed_dim))
+    pe = torch.zeros(max_len, embed_dim, requires_grad=False)
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe
+
+
+class transformer_enc_layer(nn.Module):
+    """ Transformer encoder layer, with multi-head self-attention and fully connected network (MLP)
+    (unet_cnns.py:107-159).  The attention runs over the batch axis, as in the reference (Appendix C.1)."""
+
+    def __init__(self, embed_dim=32, num_heads=8, mlp_dim=512, p_dropout=0.2, pos_encoding=None):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.pos_encoding = pos_encoding
+        max_len = 600
+        if pos_encoding == 'sinusoidal':
+            self.pe = _sinusoidal_pe(max_len, embed_dim)          # plain attribute, not in state_dict (Appendix C.3)
+            self.dropout_pe = Dropout(p=p_dropout)
+        elif pos_encoding == 'learnable':
+            self.pe = nn.Parameter(torch.zeros(max_len, embed_dim), requires_grad=True)
+            nn.init.kaiming_uniform_(self.pe)
+            self.dropout_pe = Dropout(p=p_dropout)
+        self.q_linear = Linear(embed_dim, embed_dim, bias=False)
+        self.v_linear = Linear(embed_dim, embed_dim, bias=False)
+        self.k_linear = Linear(embed_dim, embed_dim, bias=False)
+        self.attn = MultiheadAttention(embed_dim=embed_dim, num_heads=num_heads)
+        self.o_linear = Linear(embed_dim, embed_dim, bias=False)
+        self.mlp = nn.Sequential(
+            Linear(embed_dim, mlp_dim),
+            ReLU(),
+            Linear(mlp_dim, embed_dim)
+        )
+        self.dropout1 = Dropout(p=p_dropout)
+        self.layernorm1 = LayerNorm(normalized_shape=[embed_dim])
+        self.dropout2 = Dropout(p=p_dropout)
+        self.layernorm2 = LayerNorm(normalized_shape=[embed_dim])
+
+    def _pe_on(self, device):
+        pe = self.pe
+        if not isinstance(pe, nn.Parameter) and pe.device != device:
+            pe = self.pe = pe.to(device)
+        return pe
+
+    def forward(self, x):
+        B, E, H, W = x.shape
+        S = H * W
+        if E != self.embed_dim:
+            raise RuntimeError(f"transformer_enc_layer: expected {self.embed_dim} channels, got {E}")
+        xf = x.reshape(B, E, S)                                  # view
+        if self.pos_encoding is not None:
+            if S > self.pe.shape[0]:
+                raise RuntimeError(f"sequence of {S} positions exceeds the positional table ({self.pe.shape[0]})")
+            t = self.dropout_pe(ops.transpose_last2(xf, self._pe_on(x.device)))
+        else:
+            t = ops.transpose_last2(xf)                          # (B,S,E)
+        x1 = self.attn(self.q_linear(t), self.k_linear(t), self.v_linear(t))[0]
+        x1_proj = self.o_linear(x1)
+        x1_norm = self.layernorm1(t, self.dropout1(x1_proj))
+        x2 = self.mlp[2](self.mlp[0](x1_norm, ops.ACT_RELU))
+        x2_norm = self.layernorm2(x1_norm, self.dropout2(x2))
+        return ops.transpose_last2(x2_norm).reshape(B, E, H, W)
+
+
+class blstm_temporal_enc_layer(nn.Module):
+    """ BLSTM layer over time dimension (unet_cnns.py:220-243); ignores batch_first / bidirectional like the
+    reference does (always True, :232)."""
+
+    def __init__(self, embed_dim=32, hidden_size=512, num_layers=1, batch_first=True, bidirectional=True):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.hidden_size = hidden_size
+        self.num_layers = num_layers
+        self.blstm = LSTM(input_size=embed_dim, hidden_size=hidden_size, num_layers=num_layers, batch_first=True,
+                          bidirectional=True)
+
+    def forward(self, x):
+        B, C, T, Fq = x.shape
+        if C * Fq != self.embed_dim or 2 * self.hidden_size != self.embed_dim:
+            raise RuntimeError(f"blstm_temporal_enc_layer: needs C*F' == embed_dim == 2*hidden_size, got C*F'={C * Fq}, "
+                               f"embed_dim={self.embed_dim}, hidden_size={self.hidden_size}")
+        # x.transpose(2,3) -> (B,C,F',T) -> flatten(C,F') -> (B,C*F',T) -> transpose -> (B,T,C*F')
+        xt = ops.transpose_last2(x.reshape(B * C, T, Fq)).reshape(B, C * Fq, T)
+        seq = ops.transpose_last2(xt)                              # (B,T,C*F')
+        out = self.blstm(seq)[0]                                   # (B,T,2H)
+        y = ops.transpose_last2(out).reshape(B * C, Fq, T)         # (B,2H,T) viewed (B,C,F',T)
+        return ops.transpose_last2(y).reshape(B, C, T, Fq)
+
+
+class _UNetTrunk(nn.Module):
+    """Layers shared by simple_u_net_largekernels and its descendants (unet_cnns.py:345-393)."""
+
+    def _build_trunk(self, n_in, n_ch, n_bins_in, n_bins_out, a_lrelu, p_dropout, sc, convdrop=0, residual=False,
+                     alt_order=False, inc_alt_order=False):
+        self.layernorm = LayerNorm(normalized_shape=[n_in, n_bins_in])
+        kw = dict(convdrop=convdrop, residual=residual, alt_order=alt_order)
+        self.inc = double_conv(in_channels=n_in, mid_channels=64 // sc, out_channels=64 // sc, kernel_size=(15, 15),
+                               padding=(7, 7), convdrop=convdrop, alt_order=inc_alt_order)
+        self.down1 = nn.Sequential(MaxPool2d((2, 2)), double_conv(in_channels=64 // sc, out_channels=128 // sc, mid_channels=128 // sc, kernel_size=(15, 15), padding=(7, 7), **kw))
+        self.down2 = nn.Sequential(MaxPool2d((2, 2)), double_conv(in_channels=128 // sc, out_channels=256 // sc, mid_channels=256 // sc, kernel_size=(9, 9), padding=(4, 4), **kw))
+        self.down3 = nn.Sequential(MaxPool2d((2, 2)), double_conv(in_channels=256 // sc, out_channels=512 // sc, mid_channels=512 // sc, kernel_size=(5, 5), padding=(2, 2), **kw))
+        self.down4 = nn.Sequential(MaxPool2d((2, 2)), double_conv(in_channels=512 // sc, out_channels=1024 // (sc * 2), mid_channels=1024 // (sc * 2), kernel_size=(3, 3), padding=(1, 1), **kw))
+
+    def _build_decoder(self, n_ch, n_bins_in, n_bins_out, a_lrelu, p_dropout, sc, convdrop=0, residual=False,
+                       alt_order=False):
+        kw = dict(convdrop=convdrop, residual=residual, alt_order=alt_order)
+        self.upconcat = unet_up_concat_padding((2, 2))
+        self.upconv1 = double_conv(in_channels=1024 // sc, out_channels=512 // (sc * 2), mid_channels=1024 // (sc * 2), kernel_size=(3, 3), padding=(1, 1), **kw)
+        self.upconv2 = double_conv(in_channels=512 // sc, out_channels=256 // (sc * 2), mid_channels=512 // (sc * 2), kernel_size=(5, 5), padding=(2, 2), **kw)
+        self.upconv3 = double_conv(in_channels=256 // sc, out_channels=128 // (sc * 2), mid_channels=256 // (sc * 2), kernel_size=(9, 9), padding=(4, 4), **kw)
+        self.upconv4 = double_conv(in_channels=128 // sc, out_channels=n_ch[0], mid_channels=128 // (sc * 2), kernel_size=(15, 15), padding=(7, 7), **kw)
+        self.conv2, self.conv3, self.conv4 = _head(n_ch[0], n_ch, n_bins_in, n_bins_out, a_lrelu, p_dropout)
+
+    def _encode(self, x):
+        x_norm = self.layernorm.forward_cf(x)
+        x1 = self.inc(x_norm)
+        x2 = self.down1(x1)
+        x3 = self.down2(x2)
+        x4 = self.down3(x3)
+        x5 = self.down4(x4)
+        return x1, x2, x3, x4, x5
+
+    def _decode(self, x1, x2, x3, x4, x5):
+        x = self.upconv1(self.upconcat(x5, x4))
+        x = self.upconv2(self.upconcat(x, x3))
+        x = self.upconv3(self.upconcat(x, x2))
+        x = self.upconv4(self.upconcat(x, x1))
+        conv2_lrelu = self.conv2(x)
+        conv3_lrelu = self.conv3(conv2_lrelu)
+        y_pred = self.conv4(conv3_lrelu)
+        return y_pred
+
+
+class simple_u_net_largekernels(_UNetTrunk):
+    """unet_cnns.py:333-407 (Unet:S..XL, exp160*)."""
+
+    def __init__(self, n_chan_input=6, n_chan_layers=[64, 30, 20, 10], n_bins_in=216,
+                 n_bins_out=12, a_lrelu=0.3, p_dropout=0.2, scalefac=16):
+        super().__init__()
+        self._build_trunk(n_chan_input, n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, scalefac)
+        self._build_decoder(n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, scalefac)
+
+    def forward(self, x):
+        return self._decode(*self._encode(x))
+
+
+class simple_u_net_doubleselfattn(_UNetTrunk):
+    """unet_cnns.py:496-575 (SAUnet, exp180*): two transformer encoder layers on the bottleneck x5."""
+
+    def __init__(self, n_chan_input=6, n_chan_layers=[64, 30, 20, 10], n_bins_in=216, n_bins_out=12,
+                 a_lrelu=0.3, p_dropout=0.2, convdrop=0, residual=False, alt_order=False, scalefac=16, embed_dim=4 * 8,
+                 num_heads=8, mlp_dim=512, pos_encoding=None):
+        super().__init__()
+        sc = scalefac
+        self._build_trunk(n_chan_input, n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, sc, convdrop, residual,
+                          alt_order, inc_alt_order=alt_order)
+        # note: built with the class default p_dropout=0.2, not the model's p_dropout (unet_cnns.py:528-529)
+        self.attention1 = transformer_enc_layer(embed_dim=embed_dim, num_heads=num_heads, mlp_dim=mlp_dim, pos_encoding=pos_encoding)
+        self.attention2 = transformer_enc_layer(embed_dim=embed_dim, num_heads=num_heads, mlp_dim=mlp_dim)
+        self._build_decoder(n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, sc, convdrop, residual, alt_order)
+
+    def forward(self, x):
+        x1, x2, x3, x4, x5 = self._encode(x)
+        x5 = self.attention1(x5)
+        x5 = self.attention2(x5)
+        return self._decode(x1, x2, x3, x4, x5)
+
+
+class simple_u_net_doubleselfattn_twolayers(_UNetTrunk):
+    """unet_cnns.py:670-754 (SAUSnet, exp181*): attention1/2 on x5 and attention3/4 on the skip x4."""
+
+    def __init__(self, n_chan_input=6, n_chan_layers=[64, 30, 20, 10], n_bins_in=216, n_bins_out=12,
+                 a_lrelu=0.3, p_dropout=0.2, convdrop=0, residual=False, scalefac=16, embed_dim=4 * 8, num_heads=8,
+                 mlp_dim=512, pos_encoding=None):
+        super().__init__()
+        sc = scalefac
+        self._build_trunk(n_chan_input, n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, sc, convdrop, residual)
+        self.attention1 = transformer_enc_layer(embed_dim=embed_dim, num_heads=num_heads, mlp_dim=mlp_dim, p_dropout=p_dropout, pos_encoding=pos_encoding)
+        self.attention2 = transformer_enc_layer(embed_dim=embed_dim, num_heads=num_heads, mlp_dim=mlp_dim, p_dropout=p_dropout)
+        self.attention3 = transformer_enc_layer(embed_dim=embed_dim, num_heads=num_heads, mlp_dim=mlp_dim, p_dropout=p_dropout, pos_encoding=pos_encoding)
+        self.attention4 = transformer_enc_layer(embed_dim=embed_dim, num_heads=num_heads, mlp_dim=mlp_dim, p_dropout=p_dropout)
+        self._build_decoder(n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, sc, convdrop, residual)
+
+    def forward(self, x):
+        x1, x2, x3, x4, x5 = self._encode(x)
+        x5 = self.attention1(x5)
+        x5 = self.attention2(x5)
+        x4 = self.attention3(x4)
+        x4 = self.attention4(x4)
+        return self._decode(x1, x2, x3, x4, x5)
+
+
+class u_net_blstm_varlayers(_UNetTrunk):
+    """unet_cnns.py:1000-1101 (BLUnet, exp186*): BiLSTM over time on the bottleneck (and optionally the skips)."""
+
+    def __init__(self, n_chan_input=6, n_chan_layers=[64, 30, 20, 10], n_bins_in=216, n_bins_out=12, a_lrelu=0.3,
+                 p_dropout=0.2, scalefac=8, embed_dim=4 * 16, hidden_size=512, lstm_depth=0, lstm_number=2):
+        super().__init__()
+        self.lstm_depth = lstm_depth
+        self.lstm_number = lstm_number
+        self._build_trunk(n_chan_input, n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, scalefac)
+        for depth, name in ((0, "lstm5"), (1, "lstm4"), (2, "lstm3"), (3, "lstm2"), (4, "lstm1")):
+            if lstm_depth > depth:
+                setattr(self, name, blstm_temporal_enc_layer(embed_dim=embed_dim, hidden_size=hidden_size,
+                                                             num_layers=lstm_number, batch_first=True, bidirectional=True))
+        self._build_decoder(n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, scalefac)
+
+    def forward(self, x):
+        x1, x2, x3, x4, x5 = self._encode(x)
+        if self.lstm_depth > 0:
+            x5 = self.lstm5(x5)
+        if self.lstm_depth > 1:
+            x4 = self.lstm4(x4)
+        x = self.upconv1(self.upconcat(x5, x4))
+        if self.lstm_depth > 2:
+            x3 = self.lstm3(x3)
+        x = self.upconv2(self.upconcat(x, x3))
+        if self.lstm_depth > 3:
+            x2 = self.lstm2(x2)
+        x = self.upconv3(self.upconcat(x, x2))
+        if self.lstm_depth > 4:
+            x1 = self.lstm1(x1)
+        x = self.upconv4(self.upconcat(x, x1))
+        conv2_lrelu = self.conv2(x)
+        conv3_lrelu = self.conv3(conv2_lrelu)
+        y_pred = self.conv4(conv3_lrelu)
+        return y_pred
+
+
+class _PolyHead(nn.Sequential):
+    """convP: Conv(2,5) + LeakyReLU + MaxPool(2,5)/s(1,2) + Dropout + Conv(2,3) (unet_cnns.py:2311-2318)."""
+
+    def forward(self, x):
+        conv_a, act, pool, drop, conv_b = list(self)
+        return conv_b(drop(pool(conv_a(x, act.act, act.slope))))
+
+
+class simple_u_net_polyphony_classif_softmax(_UNetTrunk):
+    """unet_cnns.py:2251-2335 (PUnet, exp195*): returns (y_pred, n_pred) with degree-of-polyphony logits."""
+
+    def __init__(self, n_chan_input=6, n_chan_layers=[64, 30, 20, 10], n_bins_in=216, n_bins_out=12,
+                 a_lrelu=0.3, p_dropout=0.2, scalefac=16, num_polyphony_steps=24):
+        super().__init__()
+        sc = scalefac
+        self._build_trunk(n_chan_input, n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, sc)
+        self._build_decoder(n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, sc)
+        self.convP = _PolyHead(
+            Conv2d(1024 // (sc * 2), 1024 // (sc * 4), kernel_size=(2, 5), padding=(0, 0), stride=(1, 1)),
+            LeakyReLU(negative_slope=a_lrelu),
+            MaxPool2d(kernel_size=(2, 5), stride=(1, 2), padding=(0, 0)),
+            Dropout(p=p_dropout),
+            Conv2d(1024 // (sc * 4), num_polyphony_steps, kernel_size=(2, 3), padding=(0, 0), stride=(1, 1)))
+
+    def forward(self, x):
+        x1, x2, x3, x4, x5 = self._encode(x)
+        y_pred = self._decode(x1, x2, x3, x4, x5)
+        n_pred = self.convP(x5)
+        return y_pred, n_pred

@@ -1,0 +1,686 @@
+"""torch.autograd.Function wrappers over the C ABI of libmpa_hip.so.
+
+PyTorch provides device memory (caching allocator), the current HIP stream and
+the autograd tape only; every arithmetic op below runs in a hand-written gfx950
+kernel.  There is deliberately no CPU / eager-PyTorch fallback: CPU tensors or a
+missing library raise.
+"""
+import ctypes
+import weakref
+
+import torch
+
+from . import _lib as L
+from ._lib import ConvDesc
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
+BN_EPS = 1e-5
+LN_EPS = 1e-5
+
+
+# --------------------------------------------------------------------------- plumbing
+def _lib():
+    return L.load()
+
+
+def _c(t, name="tensor"):
+    """contiguous fp32 HIP tensor or raise (no fallback)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"multipitch_architectures_amd: {name} lives on {t.device}; the HIP kernels need a "
+                           "GPU tensor and there is no CPU fallback")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"multipitch_architectures_amd: {name} must be float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _s():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(rc, what):
+    if rc != 0:
+        L.check(rc, what)
+
+
+# parameter epoch: bumped by the fused optimizer (which writes parameters through raw pointers)
+_param_epoch = 0
+_pack_cache = {}
+
+
+def bump_param_epoch():
+    global _param_epoch
+    _param_epoch += 1
+
+
+class _Rng:
+    seed = 0x5EED
+    offset = 0
+
+
+def manual_seed(seed: int):
+    _Rng.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    _Rng.offset = 0
+
+
+def _packed(weight, desc, mode):
+    """Packed filter bank for (weight, problem geometry, fwd/bwd-data), cached until the weight changes."""
+    sig = (weight.data_ptr(), weight._version, _param_epoch)
+    ent = _pack_cache.get(id(weight))
+    if ent is None or ent[0]() is not weight or ent[1] != sig:
+        ent = (weakref.ref(weight), sig, {})
+        _pack_cache[id(weight)] = ent
+        if len(_pack_cache) > 1024:
+            for k in [k for k, v in _pack_cache.items() if v[0]() is None]:
+                del _pack_cache[k]
+    key = (desc.key()[1:], mode)
+    buf = ent[2].get(key)
+    if buf is None:
+        lib = _lib()
+        n = lib.mpa_conv2d_packed_floats(ctypes.byref(desc), mode)
+        if n < 0:
+            L.check(int(n), "mpa_conv2d_packed_floats")
+        buf = torch.empty(int(n), dtype=torch.float32, device=weight.device)
+        _chk(lib.mpa_conv2d_pack(ctypes.byref(desc), mode, _p(weight), _p(buf), _s()), "mpa_conv2d_pack")
+        ent[2][key] = buf
+    return buf
+
+
+# --------------------------------------------------------------------------- convolution
+class Conv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, act, slope):
+        x, weight, bias = _c(x, "conv input"), _c(weight, "conv weight"), _c(bias, "conv bias")
+        B, Cin, H, W = x.shape
+        Cout, Cin_w, kh, kw = weight.shape
+        if Cin_w != Cin:
+            raise RuntimeError(f"conv2d: input has {Cin} channels, weight expects {Cin_w}")
+        d = ConvDesc(B, Cin, H, W, Cout, kh, kw, stride[0], stride[1], padding[0], padding[1])
+        if d.OH <= 0 or d.OW <= 0:
+            raise RuntimeError(f"conv2d: kernel {(kh, kw)} larger than padded input {(H, W)}")
+        y = torch.empty((B, Cout, d.OH, d.OW), dtype=torch.float32, device=x.device)
+        wp = _packed(weight, d, 0)
+        _chk(_lib().mpa_conv2d_fwd(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(y), act, float(slope), _s()),
+             "mpa_conv2d_fwd")
+        ctx.desc, ctx.act, ctx.slope, ctx.has_bias = d, act, float(slope), bias is not None
+        ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        d, lib = ctx.desc, _lib()
+        dy = _c(dy, "conv grad")
+        if ctx.act != ACT_NONE:
+            g = torch.empty_like(dy)
+            _chk(lib.mpa_act_bwd(_p(dy), _p(y), _p(g), dy.numel(), ctx.act, ctx.slope, _s()), "mpa_act_bwd")
+            dy = g
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            wp = _packed(weight, d, 1)
+            _chk(lib.mpa_conv2d_bwd_data(ctypes.byref(d), _p(dy), _p(wp), _p(dx), _s()), "mpa_conv2d_bwd_data")
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty_like(weight)
+            db = torch.empty(d.Cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            nbytes = lib.mpa_conv2d_bwd_weight_workspace(ctypes.byref(d))
+            if nbytes < 0:
+                L.check(int(nbytes), "mpa_conv2d_bwd_weight_workspace")
+            ws = torch.empty(int(nbytes) // 4, dtype=torch.float32, device=x.device)
+            _chk(lib.mpa_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws), int(nbytes), _s()),
+                 "mpa_conv2d_bwd_weight")
+        return dx, dw, db, None, None, None, None
+
+
+def conv2d(x, weight, bias, stride=(1, 1), padding=(0, 0), act=ACT_NONE, slope=0.0):
+    return Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(padding), act, slope)
+
+
+# --------------------------------------------------------------------------- normalisation
+class LayerNormCFFn(torch.autograd.Function):
+    """LayerNorm([C,F]) on x.transpose(1,2) -- unet_cnns.py:560."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w, b = _c(x, "input"), _c(w), _c(b)
+        B, C, T, F = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(B * T, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        _chk(_lib().mpa_layernorm_cf_fwd(_p(x), _p(w), _p(b), _p(y), _p(mean), _p(rstd), B, C, T, F, LN_EPS, _s()),
+             "mpa_layernorm_cf_fwd")
+        ctx.save_for_backward(x, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        dy = _c(dy)
+        B, C, T, F = x.shape
+        lib = _lib()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw, db = torch.empty_like(w), torch.empty_like(w)
+        ws = torch.empty(lib.mpa_layernorm_bwd_workspace(C * F) // 4, dtype=torch.float32, device=x.device)
+        _chk(lib.mpa_layernorm_cf_bwd_ws(_p(dy), _p(x), _p(w), _p(mean), _p(rstd), _p(dx), _p(dw), _p(db), _p(ws),
+                                        B, C, T, F, _s()), "mpa_layernorm_cf_bwd_ws")
+        return dx, dw, db
+
+
+def layernorm_cf(x, w, b):
+    return LayerNormCFFn.apply(x, w, b)
+
+
+class LayerNormRowsFn(torch.autograd.Function):
+    """y = LayerNorm_E(a + r) over the last dim (unet_cnns.py:156,158); r may be None."""
+
+    @staticmethod
+    def forward(ctx, a, r, w, b):
+        a, r, w, b = _c(a), _c(r), _c(w), _c(b)
+        E = a.shape[-1]
+        rows = a.numel() // E
+        y = torch.empty_like(a)
+        xs = torch.empty_like(a) if r is not None else a
+        mean = torch.empty(rows, dtype=torch.float32, device=a.device)
+        rstd = torch.empty_like(mean)
+        _chk(_lib().mpa_layernorm_rows_fwd(_p(a), _p(r), _p(w), _p(b), _p(xs) if r is not None else None, _p(y),
+                                          _p(mean), _p(rstd), rows, E, LN_EPS, _s()), "mpa_layernorm_rows_fwd")
+        ctx.has_r = r is not None
+        ctx.save_for_backward(xs, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, w, mean, rstd = ctx.saved_tensors
+        dy = _c(dy)
+        E = xs.shape[-1]
+        rows = xs.numel() // E
+        lib = _lib()
+        dx = torch.empty_like(xs)
+        dw, db = torch.empty_like(w), torch.empty_like(w)
+        ws = torch.empty(lib.mpa_layernorm_bwd_workspace(E) // 4, dtype=torch.float32, device=xs.device)
+        _chk(lib.mpa_layernorm_rows_bwd_ws(_p(dy), _p(xs), _p(w), _p(mean), _p(rstd), _p(dx), _p(dw), _p(db), _p(ws),
+                                          rows, E, _s()), "mpa_layernorm_rows_bwd_ws")
+        return dx, (dx if ctx.has_r else None), dw, db
+
+
+def layernorm_rows(a, r, w, b):
+    return LayerNormRowsFn.apply(a, r, w, b)
+
+
+class BatchNormReLUFn(torch.autograd.Function):
+    """nn.BatchNorm2d (+ fused nn.ReLU) of double_conv -- unet_cnns.py:51-52."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, nbt, training, momentum, relu):
+        x, gamma, beta = _c(x), _c(gamma), _c(beta)
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        save_mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        save_invstd = torch.empty_like(save_mean)
+        lib = _lib()
+        if training:
+            ws = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+            _chk(lib.mpa_bn_relu_train_fwd(_p(x), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                                          ctypes.c_void_p(nbt.data_ptr()) if nbt is not None else None, _p(y),
+                                          _p(save_mean), _p(save_invstd), ctypes.c_void_p(ws.data_ptr()), B, C, H * W,
+                                          float(momentum), BN_EPS, int(relu), _s()), "mpa_bn_relu_train_fwd")
+        else:
+            _chk(lib.mpa_bn_relu_eval_fwd(_p(x), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(y),
+                                         _p(save_mean), _p(save_invstd), B, C, H * W, BN_EPS, int(relu), _s()),
+                 "mpa_bn_relu_eval_fwd")
+        ctx.training, ctx.relu = bool(training), bool(relu)
+        ctx.save_for_backward(x, y, gamma, save_mean, save_invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, save_mean, save_invstd = ctx.saved_tensors
+        dy = _c(dy)
+        B, C, H, W = x.shape
+        dx = torch.empty_like(x)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        ws = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+        _chk(_lib().mpa_bn_relu_bwd(_p(dy), _p(x), _p(y), _p(gamma), _p(save_mean), _p(save_invstd), _p(dx), _p(dgamma),
+                                   _p(dbeta), ctypes.c_void_p(ws.data_ptr()), B, C, H * W, int(ctx.relu),
+                                   int(ctx.training), _s()), "mpa_bn_relu_bwd")
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+def batchnorm_relu(x, gamma, beta, running_mean, running_var, nbt, training, momentum=0.1, relu=True):
+    return BatchNormReLUFn.apply(x, gamma, beta, running_mean, running_var, nbt, training, momentum, relu)
+
+
+# --------------------------------------------------------------------------- pooling / upsampling
+class MaxPool2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, s, p):
+        x = _c(x)
+        B, C, H, W = x.shape
+        OH = (H + 2 * p[0] - k[0]) // s[0] + 1
+        OW = (W + 2 * p[1] - k[1]) // s[1] + 1
+        if OH <= 0 or OW <= 0:
+            raise RuntimeError(f"max_pool2d: window {k} larger than input {(H, W)}")
+        y = torch.empty((B, C, OH, OW), dtype=torch.float32, device=x.device)
+        need = ctx.needs_input_grad[0]
+        idx = torch.empty((B, C, OH, OW), dtype=torch.int32, device=x.device) if need else None
+        _chk(_lib().mpa_maxpool2d_fwd(_p(x), _p(y), ctypes.c_void_p(idx.data_ptr()) if need else None, B, C, H, W,
+                                     k[0], k[1], s[0], s[1], p[0], p[1], _s()), "mpa_maxpool2d_fwd")
+        ctx.geom = (B, C, H, W, k, s, p)
+        ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        B, C, H, W, k, s, p = ctx.geom
+        dy = _c(dy)
+        dx = torch.empty((B, C, H, W), dtype=torch.float32, device=dy.device)
+        _chk(_lib().mpa_maxpool2d_bwd(_p(dy), ctypes.c_void_p(idx.data_ptr()), _p(dx), B, C, H, W, k[0], k[1], s[0],
+                                     s[1], p[0], p[1], _s()), "mpa_maxpool2d_bwd")
+        return dx, None, None, None
+
+
+def max_pool2d(x, kernel, stride=None, padding=(0, 0)):
+    stride = kernel if stride is None else stride
+    return MaxPool2dFn.apply(x, tuple(kernel), tuple(stride), tuple(padding))
+
+
+class UpCatFn(torch.autograd.Function):
+    """unet_up_concat_padding.forward -- unet_cnns.py:93-104."""
+
+    @staticmethod
+    def forward(ctx, x1, x2):
+        x1, x2 = _c(x1), _c(x2)
+        B, C1, H1, W1 = x1.shape
+        B2, Cs, Hs, Ws = x2.shape
+        if B != B2 or Hs < 2 * H1 or Ws < 2 * W1:
+            raise RuntimeError(f"upconcat: skip {tuple(x2.shape)} smaller than upsampled {tuple(x1.shape)}")
+        out = torch.empty((B, Cs + C1, Hs, Ws), dtype=torch.float32, device=x1.device)
+        _chk(_lib().mpa_upcat_fwd(_p(x1), _p(x2), _p(out), B, C1, H1, W1, Cs, Hs, Ws, _s()), "mpa_upcat_fwd")
+        ctx.geom = (B, C1, H1, W1, Cs, Hs, Ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, C1, H1, W1, Cs, Hs, Ws = ctx.geom
+        dout = _c(dout)
+        dx1 = torch.empty((B, C1, H1, W1), dtype=torch.float32, device=dout.device)
+        dskip = torch.empty((B, Cs, Hs, Ws), dtype=torch.float32, device=dout.device)
+        _chk(_lib().mpa_upcat_bwd(_p(dout), _p(dx1), _p(dskip), B, C1, H1, W1, Cs, Hs, Ws, _s()), "mpa_upcat_bwd")
+        return dx1, dskip
+
+
+def upconcat(x1, x2):
+    return UpCatFn.apply(x1, x2)
+
+
+# --------------------------------------------------------------------------- pointwise
+class ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        x = _c(x)
+        y = torch.empty_like(x)
+        _chk(_lib().mpa_act_fwd(_p(x), _p(y), x.numel(), act, float(slope), _s()), "mpa_act_fwd")
+        ctx.act, ctx.slope = act, float(slope)
+        ctx.save_for_backward(y)          # sign(y) == sign(x) for ReLU/LeakyReLU; sigmoid' uses y
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        _chk(_lib().mpa_act_bwd(_p(dy), _p(y), _p(dx), dy.numel(), ctx.act, ctx.slope, _s()), "mpa_act_bwd")
+        return dx, None, None
+
+
+def activation(x, act, slope=0.0):
+    return ActFn.apply(x, act, slope)
+
+
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout: Bernoulli keep mask scaled by 1/(1-p); the mask is regenerated from (seed, offset) in backward."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        x = _c(x)
+        y = torch.empty_like(x)
+        ctx.p, ctx.seed, ctx.offset = float(p), _Rng.seed, _Rng.offset
+        _Rng.offset += x.numel()
+        _chk(_lib().mpa_dropout(_p(x), _p(y), x.numel(), ctx.p, ctx.seed, ctx.offset, _s()), "mpa_dropout")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        _chk(_lib().mpa_dropout(_p(dy), _p(dx), dy.numel(), ctx.p, ctx.seed, ctx.offset, _s()), "mpa_dropout")
+        return dx, None
+
+
+def dropout(x, p, training):
+    if not training or p <= 0.0:
+        return x
+    if p >= 1.0:
+        raise RuntimeError("dropout p must be < 1")
+    return DropoutFn.apply(x, p)
+
+
+class AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        if a.shape != b.shape:
+            raise RuntimeError(f"add: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
+        y = torch.empty_like(a)
+        _chk(_lib().mpa_add(_p(a), _p(b), _p(y), a.numel(), _s()), "mpa_add")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    return AddFn.apply(a, b)
+
+
+class TransposeAddFn(torch.autograd.Function):
+    """x (B,R,C) -> (B,C,R), optionally adding a positional table pe (C,R) laid out like the output."""
+
+    @staticmethod
+    def forward(ctx, x, pe, pe_grad_rows):
+        x = _c(x)
+        B, R, C = x.shape
+        y = torch.empty((B, C, R), dtype=torch.float32, device=x.device)
+        pe_c = _c(pe) if pe is not None else None
+        _chk(_lib().mpa_transpose_add(_p(x), _p(pe_c), _p(y), B, R, C, 1 if pe is not None else 0, _s()),
+             "mpa_transpose_add")
+        ctx.geom = (B, R, C)
+        ctx.pe_rows = pe_grad_rows
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, R, C = ctx.geom
+        dy = _c(dy)
+        dx = torch.empty((B, R, C), dtype=torch.float32, device=dy.device)
+        lib = _lib()
+        _chk(lib.mpa_transpose_add(_p(dy), None, _p(dx), B, C, R, 0, _s()), "mpa_transpose_add")
+        dpe = None
+        if ctx.needs_input_grad[1]:
+            # learnable table (max_len, E): rows [:C] receive sum_b dy[b]
+            dpe = torch.zeros((ctx.pe_rows, R), dtype=torch.float32, device=dy.device)
+            _chk(lib.mpa_colsum(_p(dy), _p(dpe), B, C * R, 0, _s()), "mpa_colsum")
+        return dx, dpe, None
+
+
+def transpose_last2(x, pe=None):
+    """(B,R,C)->(B,C,R) (+pe[:C])."""
+    rows = pe.shape[0] if pe is not None else 0
+    pe_slice = pe[: x.shape[2]] if pe is not None else None
+    if pe is not None and pe.requires_grad:
+        # keep the full parameter in the graph: slicing is done by pointer (rows [:C] are a contiguous prefix)
+        return TransposeAddFn.apply(x, pe, rows)
+    return TransposeAddFn.apply(x, pe_slice, rows)
+
+
+# --------------------------------------------------------------------------- linear / attention
+def _gemm(A, lda_m, lda_k, Bm, ldb_k, ldb_n, bias, C, ldc, M, N, K, accumulate=0, act=ACT_NONE):
+    _chk(_lib().mpa_gemm(A, lda_m, lda_k, Bm, ldb_k, ldb_n, bias, C, ldc, M, N, K, accumulate, act, _s()), "mpa_gemm")
+
+
+def _ptr_off(t, off_floats=0):
+    return ctypes.c_void_p(t.data_ptr() + 4 * off_floats)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b) over the last dim -- nn.Linear (unet_cnns.py:131-141)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        x, weight, bias = _c(x), _c(weight), _c(bias)
+        N, K = weight.shape
+        if x.shape[-1] != K:
+            raise RuntimeError(f"linear: input features {x.shape[-1]} != weight in_features {K}")
+        rows = x.numel() // K
+        y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+        _gemm(_p(x), K, 1, _p(weight), 1, K, _p(bias), _p(y), N, rows, N, K, 0, act)
+        ctx.act, ctx.has_bias = act, bias is not None
+        ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        dy = _c(dy)
+        N, K = weight.shape
+        rows = x.numel() // K
+        lib = _lib()
+        if ctx.act != ACT_NONE:
+            g = torch.empty_like(dy)
+            _chk(lib.mpa_act_bwd(_p(dy), _p(y), _p(g), dy.numel(), ctx.act, 0.0, _s()), "mpa_act_bwd")
+            dy = g
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _gemm(_p(dy), N, 1, _p(weight), K, 1, None, _p(dx), K, rows, K, N)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            _gemm(_p(dy), 1, N, _p(x), K, 1, None, _p(dw), K, N, K, rows)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(N, dtype=torch.float32, device=x.device)
+            _chk(lib.mpa_colsum(_p(dy), _p(db), rows, N, 0, _s()), "mpa_colsum")
+        return dx, dw, db, None
+
+
+def linear(x, weight, bias=None, act=ACT_NONE):
+    return LinearFn.apply(x, weight, bias, act)
+
+
+class InProjFn(torch.autograd.Function):
+    """nn.MultiheadAttention's packed in-projection: q' = q Wq^T + bq etc. with W = in_proj_weight (3E,E)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, w, b):
+        q, k, v, w, b = _c(q), _c(k), _c(v), _c(w), _c(b)
+        E = q.shape[-1]
+        rows = q.numel() // E
+        outs = []
+        for i, t in enumerate((q, k, v)):
+            y = torch.empty_like(t)
+            _gemm(_p(t), E, 1, _ptr_off(w, i * E * E), 1, E, _ptr_off(b, i * E), _p(y), E, rows, E, E)
+            outs.append(y)
+        ctx.save_for_backward(q, k, v, w)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        q, k, v, w = ctx.saved_tensors
+        E = q.shape[-1]
+        rows = q.numel() // E
+        lib = _lib()
+        dw = torch.empty_like(w)
+        db = torch.empty(3 * E, dtype=torch.float32, device=q.device)
+        dins = []
+        for i, (t, g) in enumerate(((q, dq), (k, dk), (v, dv))):
+            g = _c(g)
+            dx = torch.empty_like(t)
+            _gemm(_p(g), E, 1, _ptr_off(w, i * E * E), E, 1, None, _p(dx), E, rows, E, E)
+            _gemm(_p(g), 1, E, _p(t), E, 1, None, _ptr_off(dw, i * E * E), E, E, E, rows)
+            _chk(lib.mpa_colsum(_p(g), _ptr_off(db, i * E), rows, E, 0, _s()), "mpa_colsum")
+            dins.append(dx)
+        return dins[0], dins[1], dins[2], dw, db
+
+
+class AttnBatchAxisFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(d)) v over the batch axis for every position and head (Appendix C.1)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads):
+        q, k, v = _c(q), _c(k), _c(v)
+        B, S, E = q.shape
+        o = torch.empty_like(q)
+        lse = torch.empty((S, heads, B), dtype=torch.float32, device=q.device)
+        _chk(_lib().mpa_attn_batchaxis_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), B, S, E, heads, _s()),
+             "mpa_attn_batchaxis_fwd")
+        ctx.heads = heads
+        ctx.save_for_backward(q, k, v, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        do = _c(do)
+        B, S, E = q.shape
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        _chk(_lib().mpa_attn_batchaxis_bwd(_p(q), _p(k), _p(v), _p(o), _p(lse), _p(do), _p(dq), _p(dk), _p(dv), B, S, E,
+                                          ctx.heads, _s()), "mpa_attn_batchaxis_bwd")
+        return dq, dk, dv, None
+
+
+def mha_batchaxis(q, k, v, in_w, in_b, heads):
+    qp, kp, vp = InProjFn.apply(q, k, v, in_w, in_b)
+    return AttnBatchAxisFn.apply(qp, kp, vp, heads)
+
+
+# --------------------------------------------------------------------------- BiLSTM layer
+class BLSTMLayerFn(torch.autograd.Function):
+    """One bidirectional nn.LSTM layer (batch_first) -- unet_cnns.py:232; gates i,f,g,o; h0=c0=0.
+    args: x (B,T,I), then [w_ih, w_hh, b_ih, b_hh] for the forward and the reverse direction."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        x = _c(x)
+        params = [_c(t) for t in params]
+        B, T, I = x.shape
+        H = params[1].shape[1]
+        lib = _lib()
+        dev = x.device
+        out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=dev)
+        saved = []
+        for d in range(2):
+            w_ih, w_hh, b_ih, b_hh = params[4 * d: 4 * d + 4]
+            bsum = torch.empty_like(b_ih)
+            _chk(lib.mpa_add(_p(b_ih), _p(b_hh), _p(bsum), 4 * H, _s()), "mpa_add")
+            G = torch.empty((B, T, 4 * H), dtype=torch.float32, device=dev)
+            _gemm(_p(x), I, 1, _p(w_ih), 1, I, _p(bsum), _p(G), 4 * H, B * T, 4 * H, I)
+            c_all = torch.empty((T, B, H), dtype=torch.float32, device=dev)
+            acts = torch.empty((T, B, 4 * H), dtype=torch.float32, device=dev)
+            order = list(range(T)) if d == 0 else list(range(T - 1, -1, -1))
+            prev = None
+            for t in order:
+                if prev is not None:
+                    # gates_t += h_prev W_hh^T ; h_prev = out[:, prev, d*H:(d+1)*H]
+                    _gemm(_ptr_off(out, prev * 2 * H + d * H), T * 2 * H, 1, _p(w_hh), 1, H, None,
+                          _ptr_off(G, t * 4 * H), T * 4 * H, B, 4 * H, H, accumulate=1)
+                _chk(lib.mpa_lstm_cell_fwd(_ptr_off(G, t * 4 * H), T * 4 * H,
+                                           _ptr_off(c_all, prev * B * H) if prev is not None else None,
+                                           _ptr_off(c_all, t * B * H), _ptr_off(out, t * 2 * H + d * H), T * 2 * H,
+                                           _ptr_off(acts, t * B * 4 * H), B, H, _s()), "mpa_lstm_cell_fwd")
+                prev = t
+            saved += [c_all, acts]
+        ctx.geom = (B, T, I, H)
+        ctx.save_for_backward(x, out, *params, *saved)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, T, I, H = ctx.geom
+        tens = ctx.saved_tensors
+        x, out = tens[0], tens[1]
+        params, saved = tens[2:10], tens[10:]
+        dout = _c(dout)
+        lib = _lib()
+        dev = x.device
+        dx = torch.empty_like(x)
+        grads = []
+        for d in range(2):
+            w_ih, w_hh, b_ih, b_hh = params[4 * d: 4 * d + 4]
+            c_all, acts = saved[2 * d: 2 * d + 2]
+            dG = torch.empty((B, T, 4 * H), dtype=torch.float32, device=dev)
+            dh_rec = torch.empty((B, H), dtype=torch.float32, device=dev)
+            dc = [torch.empty((B, H), dtype=torch.float32, device=dev) for _ in range(2)]
+            order = list(range(T)) if d == 0 else list(range(T - 1, -1, -1))
+            dw_hh = torch.zeros_like(w_hh)
+            have_next = False
+            for pos in range(T - 1, -1, -1):
+                t = order[pos]
+                prev = order[pos - 1] if pos > 0 else None
+                _chk(lib.mpa_lstm_cell_bwd(_ptr_off(dout, t * 2 * H + d * H), T * 2 * H,
+                                           _p(dh_rec) if have_next else None,
+                                           _p(dc[(pos + 1) % 2]) if have_next else None,
+                                           _ptr_off(acts, t * B * 4 * H),
+                                           _ptr_off(c_all, prev * B * H) if prev is not None else None,
+                                           _ptr_off(c_all, t * B * H), _ptr_off(dG, t * 4 * H), T * 4 * H,
+                                           _p(dc[pos % 2]), B, H, _s()), "mpa_lstm_cell_bwd")
+                if prev is not None:
+                    # dh_rec = dgates_t W_hh ; dW_hh += dgates_t^T h_prev
+                    _gemm(_ptr_off(dG, t * 4 * H), T * 4 * H, 1, _p(w_hh), H, 1, None, _p(dh_rec), H, B, H, 4 * H)
+                    _gemm(_ptr_off(dG, t * 4 * H), 1, T * 4 * H, _ptr_off(out, prev * 2 * H + d * H), T * 2 * H, 1, None,
+                          _p(dw_hh), H, 4 * H, H, B, accumulate=1)
+                have_next = True
+            dw_ih = torch.empty_like(w_ih)
+            _gemm(_p(dG), 1, 4 * H, _p(x), I, 1, None, _p(dw_ih), I, 4 * H, I, B * T)
+            db = torch.empty_like(b_ih)
+            _chk(lib.mpa_colsum(_p(dG), _p(db), B * T, 4 * H, 0, _s()), "mpa_colsum")
+            _gemm(_p(dG), 4 * H, 1, _p(w_ih), I, 1, None, _p(dx), I, B * T, I, 4 * H, accumulate=d)
+            grads += [dw_ih, dw_hh, db, db]
+        return (dx if ctx.needs_input_grad[0] else None, *grads)
+
+
+def blstm_layer(x, params):
+    return BLSTMLayerFn.apply(x, *params)
+
+
+# --------------------------------------------------------------------------- losses
+class BCELossFn(torch.autograd.Function):
+    """torch.nn.BCELoss(reduction='mean') -- exp126a_musicnet_cnn_basic.py:87."""
+
+    @staticmethod
+    def forward(ctx, p, y):
+        p, y = _c(p, "prediction"), _c(y, "target")
+        if p.shape != y.shape:
+            raise ValueError(f"Using a target size ({tuple(y.shape)}) that is different to the input size "
+                             f"({tuple(p.shape)}) is deprecated. Please ensure they have the same size.")
+        loss = torch.zeros((), dtype=torch.float32, device=p.device)
+        _chk(_lib().mpa_bce_fwd(_p(p), _p(y), _p(loss), p.numel(), _s()), "mpa_bce_fwd")
+        ctx.save_for_backward(p, y)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        p, y = ctx.saved_tensors
+        dp = torch.empty_like(p)
+        _chk(_lib().mpa_bce_bwd(_p(p), _p(y), _p(dp), p.numel(), _p(_c(g.reshape(1))), _s()), "mpa_bce_bwd")
+        return dp, None
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """torch.nn.CrossEntropyLoss()(logits (B,K,...1), target (B,...1)) * scale -- exp195f...py:333."""
+
+    @staticmethod
+    def forward(ctx, logits, target, scale):
+        logits = _c(logits)
+        B, K = logits.shape[0], logits.shape[1]
+        if logits.numel() != B * K:
+            raise RuntimeError("cross_entropy: only (B,K,1,1) logits are supported")
+        target = target.reshape(B).to(torch.int64).contiguous()
+        loss = torch.zeros((), dtype=torch.float32, device=logits.device)
+        dl = torch.empty_like(logits)
+        _chk(_lib().mpa_ce_fwd_bwd(_p(logits), ctypes.c_void_p(target.data_ptr()), _p(loss), _p(dl), B, K, float(scale),
+                                  _s()), "mpa_ce_fwd_bwd")
+        ctx.save_for_backward(dl)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors      # already scaled by `scale`; an upstream factor other than 1 is applied here
+        out = torch.empty_like(dl)
+        _chk(_lib().mpa_scale_by(_p(dl), _p(_c(g.reshape(1))), _p(out), dl.numel(), _s()), "mpa_scale_by")
+        return out, None, None

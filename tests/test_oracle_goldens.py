@@ -1,0 +1,116 @@
+"""Pins oracle/restate.py (the CPU restatement) against the golden vectors produced by the reference itself
+(oracle/make_goldens.py).  CPU only."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import (build_model, golden_cases, load_golden, oracle_forward, oracle_loss, rel_err, sample_idx, summarize)
+from multipitch_architectures_amd.synth import synth_batch
+from oracle import restate
+
+SLOW = {("SAUnet:L", 25, 75), ("SAUnet:L", 2, 174), ("DRCNN:L", 1, 75), ("PUnet:XL", 2, 75), ("BLUnet:XXL", 2, 75),
+        ("SAUSnet:L", 2, 75)}
+CASES = golden_cases()
+
+
+def _ids(c):
+    return f"{c[0]}-B{c[1]}-T{c[2]}"
+
+
+@pytest.mark.parametrize("case", CASES, ids=_ids)
+def test_schema_matches_reference(case):
+    name, B, T = case
+    g = load_golden(name, B, T)
+    schema = json.loads(str(g["schema"]))
+    sd = build_model(name).state_dict()
+    assert list(sd.keys()) == list(schema.keys())
+    for k, v in sd.items():
+        assert list(v.shape) == schema[k], k
+
+
+@pytest.mark.parametrize("case", CASES, ids=_ids)
+def test_oracle_forward_matches_reference(case):
+    name, B, T = case
+    if case in SLOW:
+        pytest.skip("full-size case covered by test_oracle_fullsize (slow marker)")
+    _check_forward(name, B, T)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("case", [c for c in CASES if c in SLOW], ids=_ids)
+def test_oracle_fullsize(case):
+    _check_forward(*case)
+
+
+def _check_forward(name, B, T):
+    g = load_golden(name, B, T)
+    sd = {k: v.clone() for k, v in build_model(name).state_dict().items()}
+    x, _ = synth_batch(B, T)
+    taps = {}
+    with torch.no_grad():
+        res = oracle_forward(name, sd, x, train=False, taps=taps)
+    y = res[0] if isinstance(res, tuple) else res
+    assert y.shape == g["y"].shape
+    # fp32 CPU vs fp32 CPU: different summation orders only
+    assert np.abs(y.numpy() - g["y"]).max() < 2e-5
+    assert rel_err(taps["logits"].numpy(), g["logits"]) < 1e-4
+    if isinstance(res, tuple):
+        assert rel_err(res[1].numpy(), g["n_pred"]) < 1e-4
+    for key in g.files:
+        if key.startswith("tap.") and key.endswith(".samples"):
+            tname = key.split(".")[1]
+            if tname not in taps:
+                continue
+            st, sm = summarize(taps[tname])
+            ref_st = g[f"tap.{tname}.stats"]
+            scale = max(ref_st[2], 1e-6)
+            assert np.abs(sm - g[key]).max() / scale < 1e-4, tname
+            assert abs(st[1] - ref_st[1]) / max(ref_st[1], 1e-6) < 1e-3, tname
+
+
+TRAIN_CASES = [c for c in CASES if "train.losses" in load_golden(*c).files]
+
+
+@pytest.mark.parametrize("case", [c for c in TRAIN_CASES if c not in SLOW and not c[0].endswith(":L")], ids=_ids)
+def test_oracle_train_step_matches_reference(case):
+    _check_train(*case)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("case", [c for c in TRAIN_CASES if c in SLOW or c[0].endswith(":L")], ids=_ids)
+def test_oracle_train_step_fullsize(case):
+    _check_train(*case)
+
+
+def _check_train(name, B, T):
+    g = load_golden(name, B, T)
+    sd, names = restate.split_state(build_model(name).state_dict())
+    x, y = synth_batch(B, T)
+    state = {}
+    losses = []
+    for step in range(3):
+        res = oracle_forward(name, sd, x, train=True, zero_dropout=True)
+        loss = oracle_loss(name, res, y)
+        grads = dict(zip(names, torch.autograd.grad(loss, [sd[k] for k in names])))
+        if step == 0:
+            yy = res[0] if isinstance(res, tuple) else res
+            assert np.abs(yy.detach().numpy() - g["train.y"]).max() < 2e-5
+            for k in names:
+                gn = g[f"grad.{k}.norm"]
+                gs = g[f"grad.{k}.samples"]
+                mine = grads[k].numpy().ravel()[sample_idx(grads[k].numel(), 16)]
+                tol = 2e-3 * max(float(gn) / np.sqrt(grads[k].numel()), np.abs(gs).max(), 1e-7) + 1e-7
+                assert np.abs(mine - gs).max() < tol, k
+                assert abs(float(grads[k].double().norm()) - float(gn)) < 2e-3 * float(gn) + 1e-6, k
+        restate.adamw_step({k: sd[k] for k in names}, grads, state, lr=1e-3)
+        if step == 0:
+            for key in g.files:
+                if key.startswith("bn1."):
+                    assert rel_err(sd[key[4:]].numpy(), g[key]) < 1e-5, key
+        losses.append(float(loss))
+    assert np.abs(np.array(losses) - g["train.losses"]).max() < 5e-5 * max(1.0, abs(g["train.losses"][0]))
+    for k in names:
+        ref = g[f"p3.{k}"]
+        assert abs(float(sd[k].detach().double().norm()) - ref[1]) < 1e-4 * ref[1] + 1e-6, k
