@@ -1,0 +1,174 @@
+#!/usr/bin/env python
+"""bench.py -- one "step" = one training step (forward + BCE loss + backward + gradient all-reduce + AdamW) of the
+hot path over one batch of synthetic HCQT patches.
+
+    python bench.py --gpus N --steps K --warmup W [--config SAUnet:L] [--global-batch 256] [--frames 75]
+
+Headline workload (BASELINE.json configs[3]): SAUnet:L (exp180d), global batch 256, T=75, fp32, strong scaling
+(local batch 256/N), data-parallel with RCCL gradient all-reduce.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X dense fp32-input MFMA peak (MI355X_MICROARCH.md, chip table)
+
+
+def cpu_baseline(config, frames, sample_batch=8, steps=2):
+    """Reference-equivalent CPU path (oracle/restate.py, parity-pinned to the reference) timed on the host cores."""
+    from multipitch_architectures_amd import nn_models
+    from multipitch_architectures_amd.configs import CONFIGS
+    from multipitch_architectures_amd.synth import synth_batch
+    from oracle import restate
+    cfg = CONFIGS[config]
+    torch.manual_seed(0)
+    model = getattr(nn_models, cfg["cls"])(**cfg["kwargs"])
+    sd, names = restate.split_state(model.state_dict())
+    x, y = synth_batch(sample_batch, frames, seed=1234)
+    state = {}
+    fn = restate.MODELS[cfg["cls"]]
+
+    def one():
+        res = fn(sd, x, train=True, **cfg["kwargs"])
+        loss = restate.punet_loss(res[0], res[1], y) if isinstance(res, tuple) else restate.bce_loss(res, y)
+        grads = dict(zip(names, torch.autograd.grad(loss, [sd[k] for k in names])))
+        restate.adamw_step({k: sd[k] for k in names}, grads, state, lr=cfg["lr"])
+
+    one()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": sample_batch * (frames - 74) / dt, "unit": "frames/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{steps} train steps of {config} at batch {sample_batch}, T={frames} "
+            f"(torch-CPU restatement oracle/restate.py, {dt:.2f} s/step)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="SAUnet:L")
+    ap.add_argument("--global-batch", type=int, default=256)
+    ap.add_argument("--frames", type=int, default=75)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from multipitch_architectures_amd import nn_models, ops
+    from multipitch_architectures_amd.configs import CONFIGS, TRAIN_GFLOP_PER_PATCH
+    from multipitch_architectures_amd.losses import BCELoss, PolyphonyLoss
+    from multipitch_architectures_amd.optim import AdamW
+    from multipitch_architectures_amd.parallel import GradientAverager, shard_range
+    from multipitch_architectures_amd.synth import synth_batch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = CONFIGS[args.config]
+    torch.manual_seed(0)                                    # PyTorch default init, seed 0 (timing is value independent)
+    model = getattr(nn_models, cfg["cls"])(**cfg["kwargs"]).to(dev).train()
+    if world > 1:
+        for p in model.parameters():
+            dist.broadcast(p.data, 0)
+    is_punet = cfg["cls"].endswith("polyphony_classif_softmax")
+    loss_fn = PolyphonyLoss() if is_punet else BCELoss()
+    opt = AdamW(model.parameters(), lr=cfg["lr"], betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    averager = GradientAverager(model.parameters()) if world > 1 else None
+
+    lo, hi = shard_range(args.global_batch, rank, world)
+    x, y = synth_batch(args.global_batch, args.frames, seed=1234)
+    x, y = x[lo:hi].to(dev), y[lo:hi].to(dev)               # inputs resident in HBM before the timed region
+    ops.manual_seed(1234 + rank)
+
+    def step():
+        res = model(x)
+        loss = loss_fn(res[0], res[1], y) if is_punet else loss_fn(res, y)
+        opt.zero_grad()
+        loss.backward()
+        if averager is not None:
+            averager.finish()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    # live roofline probe: the dominant kernel = the widest 15x15 forward conv (upconv4.double_conv.4: 16->128)
+    dom = max((m for m in model.modules() if isinstance(m, nn_models.layers.Conv2d)),
+              key=lambda m: m.in_channels * m.out_channels * m.kernel_size[0] * m.kernel_size[1] *
+              (1 if m.kernel_size[0] == 15 else 0))
+    dkey = (dom.in_channels, dom.out_channels, dom.kernel_size)
+    ops.set_kernel_probe(lambda k, kind: kind == "fwd" and (k[1], k[4], (k[5], k[6])) == dkey)
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    probe_ms = ops.probe_results_ms()
+    ops.set_kernel_probe(None)
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        patches_per_s = args.global_batch / (dt / args.steps)
+        frames_per_s = patches_per_s * (args.frames - 74)
+        B_loc = hi - lo
+        H, W = args.frames, 216
+        kflops = 2.0 * B_loc * dom.out_channels * dom.in_channels * dom.kernel_size[0] * dom.kernel_size[1] * H * W
+        kms = sum(probe_ms) / max(len(probe_ms), 1)
+        achieved = kflops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+        out = {
+            "metric": "HCQT frames/sec (train step), SAUnet:L" if args.config == "SAUnet:L" else f"HCQT frames/sec (train step), {args.config}",
+            "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "patches_per_s": patches_per_s, "loss": float(loss),
+            "config": {"workload": f"{args.config} ({cfg['cls']}) train step fwd+bwd+AdamW, global batch "
+                                   f"{args.global_batch}, patches (6,{args.frames},216) -> ({args.frames - 74},72), "
+                                   f"BASELINE.json configs[3]", "global_batch": args.global_batch,
+                       "frames": args.frames, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": f"conv_fwd_kernel {dom.in_channels}->{dom.out_channels} 15x15 @{H}x{W} "
+                                   f"(upconv4.double_conv.4), local batch {B_loc}", "launch_ms": kms,
+                         "launches_timed": len(probe_ms), "algorithmic_gflop_per_launch": kflops / 1e9},
+        }
+        if args.config in TRAIN_GFLOP_PER_PATCH:
+            step_tflops = TRAIN_GFLOP_PER_PATCH[args.config] * patches_per_s / 1e3
+            out["step_tflops"] = step_tflops
+            out["step_mfma_frac"] = step_tflops / (PEAK_FP32_MFMA_TFLOPS * world)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.config, args.frames)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -55,27 +55,34 @@ FwdPlan plan_fwd(int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw
   for (int pi = 0; pi < 4; ++pi) {
     const int PB = pbs[pi], P = PB * 64;
     for (int TH = 1; TH <= std::min(OH, P); ++TH) {
-      int TW = std::min(OW, P / TH);
-      if (TW < 1) continue;
-      // shrink TW so that tiles divide OW evenly
-      int tx = (int)mpa_cdiv(OW, TW);
-      TW = (int)mpa_cdiv(OW, tx);
-      const int ty = (int)mpa_cdiv(OH, TH);
-      const int IH = (TH - 1) * sh + kh, IW = (TW - 1) * sw + kw;
-      int LW = (sw == 1 && kw - 1 <= 32) ? TW + 32 : IW;      // row pitch == TW (mod 32): wrapped pixel blocks stay conflict-free
-      if (LW < IW) LW = IW;
-      const int CHP = round_mod(IH * LW, 32, 16);
-      // channel chunk
-      int CK = 4;
-      while (CK < 32 && CK < cin4 && kw * (CK / 4) < 15) CK *= 2;
-      while (CK > 4 && (size_t)(CK * CHP + kw * CK * COTP) * 4 > 64 * 1024) CK /= 2;
-      const size_t lds = (size_t)(CK * CHP + kw * CK * COTP) * 4;
-      if (lds > 64 * 1024) continue;
-      double cost = (double)ty * tx * P * (1.0 + 0.05 * IH * IW / P + 0.15 * (NB + PB) / (double)(NB * PB));
-      if (cost < bestcost) {
-        bestcost = cost;
-        best = FwdPlan{NB, PB, TH, TW, ty, tx, CK, (int)mpa_cdiv(Cin, CK), IH, IW, LW, CHP, COT, COTP,
-                       (int)mpa_cdiv(Cout, COT), OH, OW, lds, true};
+      const int TWmax = std::min(OW, P / TH);
+      if (TWmax < 1) continue;
+      const int tx0 = (int)mpa_cdiv(OW, TWmax);
+      for (int txi = 0; txi < 10; ++txi) {
+        // candidate tile widths: the widest that fits, then progressively narrower ones (LDS-limited tall kernels)
+        const int tx = txi < 6 ? tx0 + txi : tx0 << (txi - 4);
+        if (tx > OW) break;
+        const int TW = (int)mpa_cdiv(OW, tx);
+        const int ty = (int)mpa_cdiv(OH, TH);
+        const int IH = (TH - 1) * sh + kh, IW = (TW - 1) * sw + kw;
+        for (int lwi = 0; lwi < 2; ++lwi) {
+          // row pitch == TW (mod 32) keeps pixel blocks that wrap a row conflict-free; fall back to the tight pitch
+          int LW = (lwi == 0 && sw == 1 && kw - 1 <= 32) ? TW + 32 : (IW | 1);
+          if (LW < IW) LW = IW | 1;
+          const int CHP = round_mod(IH * LW, 32, 16);
+          int CK = 4;
+          while (CK < 32 && CK < cin4 && kw * (CK / 4) < 15) CK *= 2;
+          while (CK > 4 && (size_t)(CK * CHP + kw * CK * COTP) * 4 > 64 * 1024) CK /= 2;
+          const size_t lds = (size_t)(CK * CHP + kw * CK * COTP) * 4;
+          if (lds > 64 * 1024) continue;
+          double cost = (double)ty * tx * P * (1.0 + 0.05 * IH * IW / P + 0.15 * (NB + PB) / (double)(NB * PB)) *
+                        (1.0 + 0.02 * lwi + 0.3 / (kw * (CK / 4)));
+          if (cost < bestcost) {
+            bestcost = cost;
+            best = FwdPlan{NB, PB, TH, TW, ty, tx, CK, (int)mpa_cdiv(Cin, CK), IH, IW, LW, CHP, COT, COTP,
+                           (int)mpa_cdiv(Cout, COT), OH, OW, lds, true};
+          }
+        }
       }
     }
   }

@@ -91,6 +91,33 @@ def _packed(weight, desc, mode):
     return buf
 
 
+# optional HIP-event probe around one class of conv launches (bench.py's live roofline measurement)
+class _Probe:
+    match = None        # callable(desc_key, kind) -> bool
+    records = []        # (start_event, end_event)
+
+
+def set_kernel_probe(match):
+    _Probe.match = match
+    _Probe.records = []
+
+
+def probe_results_ms():
+    torch.cuda.synchronize()
+    return [a.elapsed_time(b) for a, b in _Probe.records]
+
+
+def _probed(kind, desc, fn):
+    if _Probe.match is not None and _Probe.match(desc.key(), kind):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = fn()
+        b.record()
+        _Probe.records.append((a, b))
+        return rc
+    return fn()
+
+
 # --------------------------------------------------------------------------- convolution
 class Conv2dFn(torch.autograd.Function):
     @staticmethod
@@ -105,8 +132,8 @@ class Conv2dFn(torch.autograd.Function):
             raise RuntimeError(f"conv2d: kernel {(kh, kw)} larger than padded input {(H, W)}")
         y = torch.empty((B, Cout, d.OH, d.OW), dtype=torch.float32, device=x.device)
         wp = _packed(weight, d, 0)
-        _chk(_lib().mpa_conv2d_fwd(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(y), act, float(slope), _s()),
-             "mpa_conv2d_fwd")
+        _chk(_probed("fwd", d, lambda: _lib().mpa_conv2d_fwd(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(y), act,
+                                                             float(slope), _s())), "mpa_conv2d_fwd")
         ctx.desc, ctx.act, ctx.slope, ctx.has_bias = d, act, float(slope), bias is not None
         ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
         return y
@@ -124,7 +151,8 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             wp = _packed(weight, d, 1)
-            _chk(lib.mpa_conv2d_bwd_data(ctypes.byref(d), _p(dy), _p(wp), _p(dx), _s()), "mpa_conv2d_bwd_data")
+            _chk(_probed("dgrad", d, lambda: lib.mpa_conv2d_bwd_data(ctypes.byref(d), _p(dy), _p(wp), _p(dx), _s())),
+                 "mpa_conv2d_bwd_data")
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(weight)
             db = torch.empty(d.Cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
@@ -132,13 +160,23 @@ class Conv2dFn(torch.autograd.Function):
             if nbytes < 0:
                 L.check(int(nbytes), "mpa_conv2d_bwd_weight_workspace")
             ws = torch.empty(int(nbytes) // 4, dtype=torch.float32, device=x.device)
-            _chk(lib.mpa_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws), int(nbytes), _s()),
+            _chk(_probed("wgrad", d, lambda: lib.mpa_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(db),
+                                                                       _p(ws), int(nbytes), _s())),
                  "mpa_conv2d_bwd_weight")
         return dx, dw, db, None, None, None, None
 
 
 def conv2d(x, weight, bias, stride=(1, 1), padding=(0, 0), act=ACT_NONE, slope=0.0):
-    return Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(padding), act, slope)
+    stride, padding = tuple(stride), tuple(padding)
+    kh = weight.shape[2]
+    if kh > 1 and kh == x.shape[2] and padding[0] == 0 and x.is_contiguous() and weight.is_contiguous():
+        # full-height valid kernel (conv3's (75,1) on a 75-frame patch, unet_cnns.py:545): (ci,dy) are adjacent in
+        # NCHW, so the conv is a 1 x kw conv over Cin*kh channels -- pure views, no data movement
+        B, C, H, W = x.shape
+        y = Conv2dFn.apply(x.view(B, C * H, 1, W), weight.view(weight.shape[0], C * kh, 1, weight.shape[3]), bias,
+                           (1, stride[1]), (0, padding[1]), act, slope)
+        return y
+    return Conv2dFn.apply(x, weight, bias, stride, padding, act, slope)
 
 
 # --------------------------------------------------------------------------- normalisation

@@ -1,0 +1,108 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU, RCCL all-reduce of gradients over xGMI,
+bucketed and overlapped with the rest of backward.
+
+The reference is single-GPU (exp126a_musicnet_cnn_basic.py:209-212: ``device = cuda:0``); this is build-side
+functionality required by BASELINE.json.  Semantics: the batch is sharded over ranks,
+BatchNorm statistics and the batch-axis attention stay *local* to a rank (exactly what wrapping the reference in
+``DistributedDataParallel`` would do), gradients are averaged over ranks.
+
+Why buckets sized like this: xGMI is point-to-point (7 links x ~153 GB/s per GPU), a ring all-reduce of G bytes
+moves 2(N-1)/N * G per GPU over one link pair, i.e. ~0.4 ms for SAUnet:L's 32.5 MB -- against >100 ms of backward.
+A handful of large buckets (default 16 MB) keeps every collective bandwidth-bound rather than latency-bound, and
+since the decoder's gradients (the expensive 15x15 layers) are produced first, their bucket is on the wire while the
+encoder is still back-propagating.
+"""
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+
+
+def shard_range(global_batch: int, rank: int, world: int):
+    """rank r owns patches [r*B/W, (r+1)*B/W); B must divide evenly (strong scaling of a fixed global batch)."""
+    if global_batch % world:
+        raise ValueError(f"global batch {global_batch} is not divisible by world size {world}")
+    per = global_batch // world
+    return rank * per, (rank + 1) * per
+
+
+class GradientAverager:
+    """Bucketed, overlapped gradient all-reduce.  Usage:
+
+        avg = GradientAverager(model.parameters())
+        loss.backward()            # hooks launch one async all-reduce per bucket as soon as it is complete
+        avg.finish()               # wait, scale by 1/world, expose the averaged values as p.grad
+        optimizer.step()
+    """
+
+    def __init__(self, params, bucket_bytes: int = 16 << 20, process_group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.buckets = []        # list of dict(params, flat, views, pending, handle)
+        self._owner = {}
+        # reverse registration order ~ order in which autograd produces gradients
+        cur, cur_bytes = [], 0
+        for p in reversed(self.params):
+            nbytes = p.numel() * p.element_size()
+            if cur and cur_bytes + nbytes > bucket_bytes:
+                self._add_bucket(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            self._add_bucket(cur)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    def _add_bucket(self, plist):
+        n = sum(p.numel() for p in plist)
+        flat = torch.zeros(n, dtype=plist[0].dtype, device=plist[0].device)
+        views, off = [], 0
+        for p in plist:
+            views.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        b = {"params": plist, "flat": flat, "views": views, "pending": len(plist), "handle": None}
+        for p in plist:
+            self._owner[p] = b
+        self.buckets.append(b)
+
+    def _on_grad(self, p):
+        b = self._owner[p]
+        i = next(j for j, q in enumerate(b["params"]) if q is p)
+        b["views"][i].copy_(p.grad)                    # device-to-device copy into the bucket (plumbing)
+        b["pending"] -= 1
+        if b["pending"] == 0 and self.world > 1:
+            b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self):
+        for b in self.buckets:
+            if b["pending"] != 0:
+                # parameters that received no gradient this step contribute zeros
+                for i, p in enumerate(b["params"]):
+                    if p.grad is None:
+                        b["views"][i].zero_()
+                if self.world > 1:
+                    b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        for b in self.buckets:
+            if b["handle"] is not None:
+                b["handle"].wait()
+                b["handle"] = None
+            if self.world > 1:
+                self._scale(b["flat"], 1.0 / self.world)
+            for p, v in zip(b["params"], b["views"]):
+                p.grad = v
+            b["pending"] = len(b["params"])
+
+    @staticmethod
+    def _scale(flat, alpha):
+        if flat.is_cuda:
+            import ctypes
+            rc = L.load().mpa_scale(alpha, ctypes.c_void_p(flat.data_ptr()), flat.numel(),
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            L.check(rc, "mpa_scale")
+        else:                     # gloo / CPU rehearsal of the communication logic only
+            flat.mul_(alpha)
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
