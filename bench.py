@@ -148,7 +148,7 @@ def main():
             "metric": "HCQT frames/sec (train step), SAUnet:L" if args.config == "SAUnet:L" else f"HCQT frames/sec (train step), {args.config}",
             "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic", "patches_per_s": patches_per_s, "loss": float(loss),
+            "data": "synthetic", "patches_per_s": patches_per_s, "loss": float(loss.detach()),
             "config": {"workload": f"{args.config} ({cfg['cls']}) train step fwd+bwd+AdamW, global batch "
                                    f"{args.global_batch}, patches (6,{args.frames},216) -> ({args.frames - 74},72), "
                                    f"BASELINE.json configs[3]", "global_batch": args.global_batch,

@@ -6,6 +6,9 @@ not a contiguous fp32 HIP tensor, the call raises.
 import ctypes
 import os
 
+import torch  # noqa: F401  -- must be imported BEFORE libmpa_hip.so is loaded: the library has to bind to the same
+#                        libamdhip64 that PyTorch brings, otherwise streams/pointers belong to another HIP runtime
+
 from .build import LIB, build_library
 
 c_void_p, c_int, c_int64, c_float, c_double, c_uint64 = (

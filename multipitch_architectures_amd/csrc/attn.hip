@@ -169,7 +169,7 @@ int mpa_attn_batchaxis_fwd(const float* q, const float* k, const float* v, float
                            int heads, void* stream) {
   if (!q || !k || !v || !o || !lse || heads <= 0 || E % heads || E / heads > DMAX) return MPA_ERR_ARG;
   const float scale = 1.0f / sqrtf((float)(E / heads));
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(S, heads), dim3(256), 0, (hipStream_t)stream, q, k, v, o, lse, B, S, E, heads,
+  MPA_LAUNCH(attn_fwd_kernel, dim3(S, heads), dim3(256), 0, (hipStream_t)stream, q, k, v, o, lse, B, S, E, heads,
                      scale);
   return mpa_launch_status();
 }
@@ -180,9 +180,9 @@ int mpa_attn_batchaxis_bwd(const float* q, const float* k, const float* v, const
     return MPA_ERR_ARG;
   const float scale = 1.0f / sqrtf((float)(E / heads));
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL((attn_bwd_kernel<0>), dim3(S, heads), dim3(256), 0, s, q, k, v, o, lse, do_, dq, dk, dv, B, S, E, heads,
+  MPA_LAUNCH((attn_bwd_kernel<0>), dim3(S, heads), dim3(256), 0, s, q, k, v, o, lse, do_, dq, dk, dv, B, S, E, heads,
                      scale);
-  hipLaunchKernelGGL((attn_bwd_kernel<1>), dim3(S, heads), dim3(256), 0, s, q, k, v, o, lse, do_, dq, dk, dv, B, S, E, heads,
+  MPA_LAUNCH((attn_bwd_kernel<1>), dim3(S, heads), dim3(256), 0, s, q, k, v, o, lse, do_, dq, dk, dv, B, S, E, heads,
                      scale);
   return mpa_launch_status();
 }

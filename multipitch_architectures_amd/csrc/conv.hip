@@ -191,8 +191,27 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
       for (int j = 0; j < p.CK / 4; ++j) {
         const float* ap = lds_w + j * 4 * p.COTP + aoff;
         const float* bp = lds_in + j * 4 * p.CHP + dy * p.LW;
-#pragma unroll 3
-        for (int dx = 0; dx < p.kw; ++dx) {
+        // taps in groups of 3 (kw = 15, 9, 3 for every large filter of the model): all operand reads of a group are
+        // issued before its MFMAs, the remaining latency is covered by the other resident waves
+        int dx = 0;
+        for (; dx + 3 <= p.kw; dx += 3) {
+          float a[3][NB], bv[3][PB];
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) a[u][nb] = ap[(dx + u) * astep + nb * 16];
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) bv[u][pb] = bp[boff[pb] + dx + u];
+          }
+#pragma unroll
+          for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+              for (int pb = 0; pb < PB; ++pb)
+                acc[nb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][nb], bv[u][pb], acc[nb][pb], 0, 0, 0);
+        }
+        for (; dx < p.kw; ++dx) {
           float a[NB], bv[PB];
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) a[nb] = ap[dx * astep + nb * 16];
@@ -236,10 +255,10 @@ template <int NB>
 int launch_fwd_nb(const FwdPlan& pl, const ConvFwdParams& p, hipStream_t s) {
   dim3 grid((unsigned)(p.B * pl.tilesY * pl.tilesX), (unsigned)pl.coTiles);
   switch (pl.PB) {
-    case 1: hipLaunchKernelGGL((conv_fwd_kernel<NB, 1>), grid, dim3(256), pl.lds_bytes, s, p); break;
-    case 2: hipLaunchKernelGGL((conv_fwd_kernel<NB, 2>), grid, dim3(256), pl.lds_bytes, s, p); break;
-    case 4: hipLaunchKernelGGL((conv_fwd_kernel<NB, 4>), grid, dim3(256), pl.lds_bytes, s, p); break;
-    case 6: hipLaunchKernelGGL((conv_fwd_kernel<NB, 6>), grid, dim3(256), pl.lds_bytes, s, p); break;
+    case 1: MPA_LAUNCH((conv_fwd_kernel<NB, 1>), grid, dim3(256), pl.lds_bytes, s, p); break;
+    case 2: MPA_LAUNCH((conv_fwd_kernel<NB, 2>), grid, dim3(256), pl.lds_bytes, s, p); break;
+    case 4: MPA_LAUNCH((conv_fwd_kernel<NB, 4>), grid, dim3(256), pl.lds_bytes, s, p); break;
+    case 6: MPA_LAUNCH((conv_fwd_kernel<NB, 6>), grid, dim3(256), pl.lds_bytes, s, p); break;
     default: return MPA_ERR_UNSUPPORTED;
   }
   return mpa_launch_status();
@@ -385,6 +404,7 @@ struct WgParams {
   float* ws;
   int B, Cin, H, W, Cout, OH, OW, kh, kw, sh, sw, ph, pw;
   int COT, nPerBlock, Ntot, XCH, TH, TW, DP, tilesY, tilesX, IH, IW, LW, XCHP, DCP, S;
+  int with_bias;   // workspace rows carry one extra column: sum over pixels of dY (the bias gradient)
 };
 
 template <int NBC, int NTW>
@@ -409,6 +429,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgParams p) {
     xoff[t] = (ci - ci_first) * p.XCHP + dy * p.LW + dx + kq * p.sw;
   }
   const int aoff = l16 * p.DCP + kq;
+  const int NtotP = p.Ntot + (p.with_bias ? 1 : 0);
+  const bool do_bias = p.with_bias && ntile == 0;
+  float bsum = 0.f;      // threads 2*co, 2*co+1 accumulate the bias gradient of cout co
   f32x4 acc[NBC][NTW];
 #pragma unroll
   for (int i = 0; i < NBC; ++i)
@@ -430,6 +453,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgParams p) {
     stage_window(lds_dy, p.dy + (long)b * p.Cout * p.OH * p.OW, tid, p.COT, p.TH, p.DP, p.DCP, p.DP, cot * p.COT, oy0,
                  ox0, p.Cout, p.OH, p.OW, min(p.OW, ox0 + p.TW));
     __syncthreads();
+    if (do_bias) {
+      // 2 threads per cout (COT <= 80 < 128), each summing half of the tile's pixels (zero-filled outside the image)
+      const int co = tid >> 1, part = tid & 1;
+      if (co < p.COT) {
+        const float* row = lds_dy + co * p.DCP;
+        const int npx = p.TH * p.DP;
+        float s = 0.f;
+        for (int i = part; i < npx; i += 2) s += row[i];
+        bsum += s;
+      }
+    }
     for (int py = 0; py < p.TH; ++py) {
       const float* ap = lds_dy + py * p.DP + aoff;
       const float* bp = lds_x + py * p.sh * p.LW;
@@ -449,7 +483,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgParams p) {
     }
   }
   // partial slice -> workspace [split][Cout][Ntot]
-  float* out = p.ws + (long)split * p.Cout * p.Ntot;
+  float* out = p.ws + (long)split * p.Cout * NtotP;
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
     const int n = n_base + t * 16 + l16;
@@ -459,16 +493,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = cot * p.COT + cb * 16 + kq * 4 + r;
-        if (co < p.Cout) out[(long)co * p.Ntot + n] = acc[cb][t][r];
+        if (co < p.Cout) out[(long)co * NtotP + n] = acc[cb][t][r];
       }
+  }
+  if (do_bias) {
+    bsum += __shfl_xor(bsum, 1, 64);
+    const int co = cot * p.COT + (tid >> 1);
+    if ((tid & 1) == 0 && (tid >> 1) < p.COT && co < p.Cout) out[(long)co * NtotP + p.Ntot] = bsum;
   }
 }
 
-__global__ void reduce_partials_kernel(const float* ws, float* out, long n, int S) {
+// ws [S][Cout][NtotP] -> dw [Cout][Ntot] (+ db [Cout] from the extra column)
+__global__ void reduce_partials_kernel(const float* __restrict__ ws, float* __restrict__ dw, float* __restrict__ db,
+                                       int Cout, int Ntot, int NtotP, int S) {
+  const long n = (long)Cout * NtotP;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int k = 0; k < S; ++k) s += ws[(long)k * n + i];
-    out[i] = s;
+    const int co = (int)(i / NtotP), j = (int)(i - (long)co * NtotP);
+    if (j < Ntot) dw[(long)co * Ntot + j] = s;
+    else if (db) db[co] = s;
   }
 }
 
@@ -512,7 +556,7 @@ int mpa_conv2d_pack(const mpa_conv_desc* d, int mode, const float* w, float* w_p
   p.CK = pl.CK; p.nChunks = pl.nChunks; p.COT = pl.COT; p.COTP = pl.COTP; p.coTiles = pl.coTiles;
   p.total = (long)pl.coTiles * pl.nChunks * p.kh * p.kw * pl.CK * pl.COTP;
   const int blocks = (int)std::min<long>(mpa_cdiv(p.total, 256), 4096);
-  hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  MPA_LAUNCH(conv_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
   return mpa_launch_status();
 }
 
@@ -559,17 +603,15 @@ int64_t mpa_conv2d_bwd_weight_workspace(const mpa_conv_desc* d) {
   if (!d) return MPA_ERR_ARG;
   WgPlan pl = plan_wgrad(d);
   if (!pl.ok) return MPA_ERR_UNSUPPORTED;
-  return (int64_t)pl.S * d->Cout * pl.Ntot * 4;
+  return (int64_t)pl.S * d->Cout * (pl.Ntot + 1) * 4;
 }
-
-int mpa_channel_sum(const float* x, float* out, int B, int C, int HW, void* stream);
 
 int mpa_conv2d_bwd_weight(const mpa_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
                           void* workspace, int64_t workspace_bytes, void* stream) {
   if (!d || !x || !dy || !dw || d->B <= 0) return MPA_ERR_ARG;
   WgPlan pl = plan_wgrad(d);
   if (!pl.ok) return MPA_ERR_UNSUPPORTED;
-  const int64_t need = (int64_t)pl.S * d->Cout * pl.Ntot * 4;
+  const int64_t need = (int64_t)pl.S * d->Cout * (pl.Ntot + 1) * 4;
   if (!workspace || workspace_bytes < need) return MPA_ERR_WORKSPACE;
   WgParams p{};
   p.x = x; p.dy = dy; p.ws = (float*)workspace;
@@ -578,21 +620,19 @@ int mpa_conv2d_bwd_weight(const mpa_conv_desc* d, const float* x, const float* d
   p.COT = pl.COT; p.nPerBlock = pl.nPerBlock; p.Ntot = pl.Ntot; p.XCH = pl.XCH; p.TH = pl.TH; p.TW = pl.TW; p.DP = pl.DP;
   p.tilesY = pl.tilesY; p.tilesX = pl.tilesX; p.IH = pl.IH; p.IW = pl.IW; p.LW = pl.LW; p.XCHP = pl.XCHP; p.DCP = pl.DCP;
   p.S = pl.S;
+  p.with_bias = 1;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)pl.S, (unsigned)pl.nTiles, (unsigned)pl.coTiles);
-  if (pl.NBC == 1) hipLaunchKernelGGL((conv_wgrad_kernel<1, 16>), grid, dim3(256), pl.lds_bytes, s, p);
-  else if (pl.NBC == 2) hipLaunchKernelGGL((conv_wgrad_kernel<2, 8>), grid, dim3(256), pl.lds_bytes, s, p);
-  else if (pl.NBC == 4) hipLaunchKernelGGL((conv_wgrad_kernel<4, 6>), grid, dim3(256), pl.lds_bytes, s, p);
-  else hipLaunchKernelGGL((conv_wgrad_kernel<5, 6>), grid, dim3(256), pl.lds_bytes, s, p);
+  if (pl.NBC == 1) MPA_LAUNCH((conv_wgrad_kernel<1, 16>), grid, dim3(256), pl.lds_bytes, s, p);
+  else if (pl.NBC == 2) MPA_LAUNCH((conv_wgrad_kernel<2, 8>), grid, dim3(256), pl.lds_bytes, s, p);
+  else if (pl.NBC == 4) MPA_LAUNCH((conv_wgrad_kernel<4, 6>), grid, dim3(256), pl.lds_bytes, s, p);
+  else MPA_LAUNCH((conv_wgrad_kernel<5, 6>), grid, dim3(256), pl.lds_bytes, s, p);
   int rc = mpa_launch_status();
   if (rc) return rc;
-  const long n = (long)d->Cout * pl.Ntot;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)std::min<long>(mpa_cdiv(n, 256), 2048)), dim3(256), 0, s,
-                     (const float*)workspace, dw, n, pl.S);
-  rc = mpa_launch_status();
-  if (rc) return rc;
-  if (db) return mpa_channel_sum(dy, db, d->B, d->Cout, pl.OH * pl.OW, stream);
-  return MPA_OK;
+  const long n = (long)d->Cout * (pl.Ntot + 1);
+  MPA_LAUNCH(reduce_partials_kernel, dim3((unsigned)std::min<long>(mpa_cdiv(n, 256), 2048)), dim3(256), 0, s,
+             (const float*)workspace, dw, db, d->Cout, pl.Ntot, pl.Ntot + 1, pl.S);
+  return mpa_launch_status();
 }
 
 }  // extern "C"

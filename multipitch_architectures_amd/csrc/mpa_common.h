@@ -8,6 +8,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define MPA_WAVE 64
 
+// PyTorch can leave a stale (non-fatal) error in the thread's HIP error slot; clear it before every launch so that
+// mpa_launch_status() reports this launch only.
+#define MPA_LAUNCH(...)            \
+  do {                             \
+    (void)hipGetLastError();       \
+    hipLaunchKernelGGL(__VA_ARGS__); \
+  } while (0)
+
 static inline int mpa_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MPA_OK : MPA_ERR_LAUNCH;

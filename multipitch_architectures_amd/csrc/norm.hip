@@ -372,7 +372,7 @@ int mpa_layernorm_cf_fwd(const float* x, const float* w, const float* b, float* 
                          int T, int F, float eps, void* stream) {
   if (!x || !w || !b || !y || !mean || !rstd || C * F > 64 * LNCF_MAXV) return MPA_ERR_ARG;
   const long rows = (long)B * T;
-  hipLaunchKernelGGL(layernorm_cf_fwd_kernel, dim3((unsigned)mpa_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, w, b,
+  MPA_LAUNCH(layernorm_cf_fwd_kernel, dim3((unsigned)mpa_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, w, b,
                      y, mean, rstd, B, C, T, F, eps);
   return mpa_launch_status();
 }
@@ -388,11 +388,11 @@ int mpa_layernorm_cf_bwd_ws(const float* dy, const float* x, const float* w, con
   if (!dy || !x || !w || !mean || !rstd || !dw || !db || !ws || C * F > 64 * LNCF_MAXV) return MPA_ERR_ARG;
   const int n = C * F;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(layernorm_cf_bwd_kernel, dim3(LN_BWD_BLOCKS), dim3(256), (size_t)8 * n * 4, s, dy, x, w, mean, rstd, dx,
+  MPA_LAUNCH(layernorm_cf_bwd_kernel, dim3(LN_BWD_BLOCKS), dim3(256), (size_t)8 * n * 4, s, dy, x, w, mean, rstd, dx,
                      (float*)ws, B, C, T, F);
   int rc = mpa_launch_status();
   if (rc) return rc;
-  hipLaunchKernelGGL(reduce2_kernel, dim3((unsigned)mpa_cdiv(2 * n, 256)), dim3(256), 0, s, (const float*)ws, dw, db, n,
+  MPA_LAUNCH(reduce2_kernel, dim3((unsigned)mpa_cdiv(2 * n, 256)), dim3(256), 0, s, (const float*)ws, dw, db, n,
                      LN_BWD_BLOCKS);
   return mpa_launch_status();
 }
@@ -400,7 +400,7 @@ int mpa_layernorm_cf_bwd_ws(const float* dy, const float* x, const float* w, con
 int mpa_layernorm_rows_fwd(const float* a, const float* r, const float* w, const float* b, float* sum_out, float* y,
                            float* mean, float* rstd, int64_t rows, int E, float eps, void* stream) {
   if (!a || !w || !b || !y || !mean || !rstd || E > 64 * LNR_MAXV) return MPA_ERR_ARG;
-  hipLaunchKernelGGL(layernorm_rows_fwd_kernel, dim3((unsigned)mpa_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, a, r, w,
+  MPA_LAUNCH(layernorm_rows_fwd_kernel, dim3((unsigned)mpa_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, a, r, w,
                      b, sum_out, y, mean, rstd, (long)rows, E, eps);
   return mpa_launch_status();
 }
@@ -409,11 +409,11 @@ int mpa_layernorm_rows_bwd_ws(const float* dy, const float* xs, const float* w, 
                               float* dx, float* dw, float* db, void* ws, int64_t rows, int E, void* stream) {
   if (!dy || !xs || !w || !mean || !rstd || !dx || !dw || !db || !ws || E > 64 * LNR_MAXV) return MPA_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(layernorm_rows_bwd_kernel, dim3(LN_BWD_BLOCKS), dim3(256), (size_t)8 * E * 4, s, dy, xs, w, mean, rstd,
+  MPA_LAUNCH(layernorm_rows_bwd_kernel, dim3(LN_BWD_BLOCKS), dim3(256), (size_t)8 * E * 4, s, dy, xs, w, mean, rstd,
                      dx, (float*)ws, (long)rows, E);
   int rc = mpa_launch_status();
   if (rc) return rc;
-  hipLaunchKernelGGL(reduce2_kernel, dim3((unsigned)mpa_cdiv(2 * E, 256)), dim3(256), 0, s, (const float*)ws, dw, db, E,
+  MPA_LAUNCH(reduce2_kernel, dim3((unsigned)mpa_cdiv(2 * E, 256)), dim3(256), 0, s, (const float*)ws, dw, db, E,
                      LN_BWD_BLOCKS);
   return mpa_launch_status();
 }
@@ -426,12 +426,12 @@ int mpa_bn_relu_train_fwd(const float* x, const float* gamma, const float* beta,
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * C, s) != hipSuccess) return MPA_ERR_LAUNCH;
   const int splits = stat_splits(B, C, HW);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(splits, C), dim3(256), 0, s, x, stats_ws, B, C, HW);
+  MPA_LAUNCH(bn_stats_kernel, dim3(splits, C), dim3(256), 0, s, x, stats_ws, B, C, HW);
   const double count = (double)B * HW;
   const int chunks = (int)std::max<long>(1, std::min<long>(mpa_cdiv(HW, 1024), 64));
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(B * C, chunks), dim3(256), 0, s, x, gamma, beta, (const double*)stats_ws,
+  MPA_LAUNCH(bn_apply_kernel, dim3(B * C, chunks), dim3(256), 0, s, x, gamma, beta, (const double*)stats_ws,
                      (const float*)nullptr, (const float*)nullptr, y, C, HW, count, eps, relu);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)mpa_cdiv(C, 64)), dim3(64), 0, s, (const double*)stats_ws,
+  MPA_LAUNCH(bn_finalize_kernel, dim3((unsigned)mpa_cdiv(C, 64)), dim3(64), 0, s, (const double*)stats_ws,
                      running_mean, running_var, num_batches_tracked, save_mean, save_invstd, C, count, momentum, eps);
   return mpa_launch_status();
 }
@@ -442,10 +442,10 @@ int mpa_bn_relu_eval_fwd(const float* x, const float* gamma, const float* beta, 
   if (!x || !gamma || !beta || !running_mean || !running_var || !y) return MPA_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int chunks = (int)std::max<long>(1, std::min<long>(mpa_cdiv(HW, 1024), 64));
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(B * C, chunks), dim3(256), 0, s, x, gamma, beta, (const double*)nullptr,
+  MPA_LAUNCH(bn_apply_kernel, dim3(B * C, chunks), dim3(256), 0, s, x, gamma, beta, (const double*)nullptr,
                      running_mean, running_var, y, C, HW, 1.0, eps, relu);
   if (save_mean && save_invstd)
-    hipLaunchKernelGGL(bn_eval_save_kernel, dim3((unsigned)mpa_cdiv(C, 64)), dim3(64), 0, s, running_mean, running_var,
+    MPA_LAUNCH(bn_eval_save_kernel, dim3((unsigned)mpa_cdiv(C, 64)), dim3(64), 0, s, running_mean, running_var,
                        save_mean, save_invstd, C, eps);
   return mpa_launch_status();
 }
@@ -458,12 +458,12 @@ int mpa_bn_relu_bwd(const float* dy, const float* x, const float* y, const float
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * C, s) != hipSuccess) return MPA_ERR_LAUNCH;
   const int splits = stat_splits(B, C, HW);
-  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(splits, C), dim3(256), 0, s, dy, x, y, save_mean, save_invstd, stats_ws, B, C,
+  MPA_LAUNCH(bn_bwd_stats_kernel, dim3(splits, C), dim3(256), 0, s, dy, x, y, save_mean, save_invstd, stats_ws, B, C,
                      HW, relu);
   const int chunks = (int)std::max<long>(1, std::min<long>(mpa_cdiv(HW, 1024), 64));
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(B * C, chunks), dim3(256), 0, s, dy, x, y, gamma, save_mean, save_invstd,
+  MPA_LAUNCH(bn_bwd_apply_kernel, dim3(B * C, chunks), dim3(256), 0, s, dy, x, y, gamma, save_mean, save_invstd,
                      (const double*)stats_ws, dx, C, HW, (double)B * HW, relu, train);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)mpa_cdiv(C, 64)), dim3(64), 0, s, (const double*)stats_ws, dgamma,
+  MPA_LAUNCH(bn_bwd_finalize_kernel, dim3((unsigned)mpa_cdiv(C, 64)), dim3(64), 0, s, (const double*)stats_ws, dgamma,
                      dbeta, C);
   return mpa_launch_status();
 }

@@ -124,21 +124,18 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
   if (threadIdx.x == 0) out[c] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
-// out[n] (+)= sum_rows x[row][n]; grid (ceil(N/64)); block 256 = 4 row-groups x 64 columns
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long rows, int N,
-                                                     int accumulate) {
+// out[n] += sum_rows x[row][n]; grid (ceil(N/64), row splits); block 256 = 4 row-groups x 64 columns; float atomics
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long rows, int N) {
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
   const int g = threadIdx.x >> 6;
   float s = 0.f;
   if (col < N)
-    for (long r = g; r < rows; r += 4) s += x[r * N + col];
+    for (long r = (long)blockIdx.y * 4 + g; r < rows; r += (long)gridDim.y * 4) s += x[r * N + col];
   __shared__ float sh[4][64];
   sh[g][threadIdx.x & 63] = s;
   __syncthreads();
-  if (g == 0 && col < N) {
-    const float t = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
-    out[col] = accumulate ? out[col] + t : t;
-  }
+  if (g == 0 && col < N)
+    atomicAdd(&out[col], sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
 __global__ __launch_bounds__(256) void add_rows_bcast_kernel(const float* __restrict__ x, const float* __restrict__ pe,
@@ -283,94 +280,97 @@ int mpa_version(void) { return 1; }
 int mpa_act_fwd(const float* x, float* y, int64_t n, int act, float slope, void* stream) {
   if (!x || !y) return MPA_ERR_ARG;
   if (n == 0) return MPA_OK;
-  hipLaunchKernelGGL(act_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, (long)n, act, slope);
+  MPA_LAUNCH(act_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, (long)n, act, slope);
   return mpa_launch_status();
 }
 int mpa_act_bwd(const float* dy, const float* x, float* dx, int64_t n, int act, float slope, void* stream) {
   if (!dy || !x || !dx) return MPA_ERR_ARG;
   if (n == 0) return MPA_OK;
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, dy, x, dx, (long)n, act, slope);
+  MPA_LAUNCH(act_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, dy, x, dx, (long)n, act, slope);
   return mpa_launch_status();
 }
 int mpa_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream) {
   if (!x || !y || p < 0.f || p >= 1.f) return MPA_ERR_ARG;
   if (n == 0) return MPA_OK;
-  hipLaunchKernelGGL(dropout_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, (long)n, p, 1.f / (1.f - p),
+  MPA_LAUNCH(dropout_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, (long)n, p, 1.f / (1.f - p),
                      seed, offset);
   return mpa_launch_status();
 }
 int mpa_add(const float* a, const float* b, float* y, int64_t n, void* stream) {
   if (!a || !b || !y) return MPA_ERR_ARG;
   if (n == 0) return MPA_OK;
-  hipLaunchKernelGGL(add_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, (long)n);
+  MPA_LAUNCH(add_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, (long)n);
   return mpa_launch_status();
 }
 int mpa_axpy(float alpha, const float* x, float* y, int64_t n, void* stream) {
   if (!x || !y) return MPA_ERR_ARG;
   if (n == 0) return MPA_OK;
-  hipLaunchKernelGGL(axpy_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, alpha, x, y, (long)n);
+  MPA_LAUNCH(axpy_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, alpha, x, y, (long)n);
   return mpa_launch_status();
 }
 int mpa_scale_by(const float* x, const float* g, float* y, int64_t n, void* stream) {
   if (!x || !g || !y) return MPA_ERR_ARG;
   if (n == 0) return MPA_OK;
-  hipLaunchKernelGGL(scale_by_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, g, y, (long)n);
+  MPA_LAUNCH(scale_by_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, g, y, (long)n);
   return mpa_launch_status();
 }
 int mpa_scale(float alpha, float* x, int64_t n, void* stream) {
   if (!x) return MPA_ERR_ARG;
   if (n == 0) return MPA_OK;
-  hipLaunchKernelGGL(scale_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, alpha, x, (long)n);
+  MPA_LAUNCH(scale_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, alpha, x, (long)n);
   return mpa_launch_status();
 }
 // x (B,R,Cc) -> y (B,Cc,R); pe_mode 0 none, 1 add pe (Cc,R) to the output, 2 add pe (R,Cc) to the input
 int mpa_transpose_add(const float* x, const float* pe, float* y, int B, int R, int Cc, int pe_mode, void* stream) {
   if (!x || !y || (pe_mode && !pe)) return MPA_ERR_ARG;
   dim3 grid((unsigned)mpa_cdiv(Cc, 32), (unsigned)mpa_cdiv(R, 32), (unsigned)B);
-  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, pe, y, R, Cc, pe_mode);
+  MPA_LAUNCH(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, pe, y, R, Cc, pe_mode);
   return mpa_launch_status();
 }
 int mpa_channel_sum(const float* x, float* out, int B, int C, int HW, void* stream) {
   if (!x || !out) return MPA_ERR_ARG;
-  hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, out, B, C, HW);
+  MPA_LAUNCH(channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, out, B, C, HW);
   return mpa_launch_status();
 }
 int mpa_colsum(const float* x, float* out, int64_t rows, int N, int accumulate, void* stream) {
   if (!x || !out) return MPA_ERR_ARG;
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)mpa_cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, x, out, (long)rows, N,
-                     accumulate);
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s) != hipSuccess) return MPA_ERR_LAUNCH;
+  const long colblocks = mpa_cdiv(N, 64);
+  long splits = std::max<long>(1, std::min<long>(mpa_cdiv(rows, 64), mpa_cdiv(1024, colblocks)));
+  MPA_LAUNCH(colsum_kernel, dim3((unsigned)colblocks, (unsigned)splits), dim3(256), 0, s, x, out, (long)rows, N);
   return mpa_launch_status();
 }
 int mpa_add_rows_bcast(const float* x, const float* pe, float* y, int B, int64_t SE, void* stream) {
   if (!x || !pe || !y) return MPA_ERR_ARG;
   const long n = (long)B * SE;
-  hipLaunchKernelGGL(add_rows_bcast_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, pe, y, n, (long)SE);
+  MPA_LAUNCH(add_rows_bcast_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, pe, y, n, (long)SE);
   return mpa_launch_status();
 }
 
 int mpa_bce_fwd(const float* p, const float* y, float* loss_out, int64_t n, void* stream) {
   if (!p || !y || !loss_out || n <= 0) return MPA_ERR_ARG;
-  hipLaunchKernelGGL(bce_fwd_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, y, loss_out, (long)n,
+  MPA_LAUNCH(bce_fwd_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, y, loss_out, (long)n,
                      1.0f / (float)n);
   return mpa_launch_status();
 }
 int mpa_bce_bwd(const float* p, const float* y, float* dp, int64_t n, const float* g, void* stream) {
   if (!p || !y || !dp || n <= 0) return MPA_ERR_ARG;
-  hipLaunchKernelGGL(bce_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, p, y, dp, (long)n, g,
+  MPA_LAUNCH(bce_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, p, y, dp, (long)n, g,
                      1.0f / (float)n);
   return mpa_launch_status();
 }
 int mpa_ce_fwd_bwd(const float* logits, const int64_t* target, float* loss_out, float* dlogits, int B, int K, float scale,
                    void* stream) {
   if (!logits || !target || !loss_out || B <= 0) return MPA_ERR_ARG;
-  hipLaunchKernelGGL(ce_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, logits, target, loss_out, dlogits, B, K, scale);
+  MPA_LAUNCH(ce_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, logits, target, loss_out, dlogits, B, K, scale);
   return mpa_launch_status();
 }
 
 int mpa_lstm_cell_fwd(const float* gates, int64_t g_stride, const float* c_prev, float* c, float* h, int64_t h_stride,
                       float* acts, int B, int H, void* stream) {
   if (!gates || !c || !h || !acts) return MPA_ERR_ARG;
-  hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(blocks_for((long)B * H)), dim3(256), 0, (hipStream_t)stream, gates,
+  MPA_LAUNCH(lstm_cell_fwd_kernel, dim3(blocks_for((long)B * H)), dim3(256), 0, (hipStream_t)stream, gates,
                      (long)g_stride, c_prev, c, h, (long)h_stride, acts, B, H);
   return mpa_launch_status();
 }
@@ -378,7 +378,7 @@ int mpa_lstm_cell_bwd(const float* dh, int64_t dh_stride, const float* dh_rec, c
                       const float* c_prev, const float* c, float* dgates, int64_t dg_stride, float* dc_prev, int B, int H,
                       void* stream) {
   if (!dh || !acts || !c || !dgates || !dc_prev) return MPA_ERR_ARG;
-  hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(blocks_for((long)B * H)), dim3(256), 0, (hipStream_t)stream, dh,
+  MPA_LAUNCH(lstm_cell_bwd_kernel, dim3(blocks_for((long)B * H)), dim3(256), 0, (hipStream_t)stream, dh,
                      (long)dh_stride, dh_rec, dc_next, acts, c_prev, c, dgates, (long)dg_stride, dc_prev, B, H);
   return mpa_launch_status();
 }
@@ -390,7 +390,7 @@ int mpa_adamw_step(float* const* params, const float* const* grads, float* const
   const double bc1 = 1.0 - pow(beta1, (double)step);
   const double bc2 = 1.0 - pow(beta2, (double)step);
   dim3 grid((unsigned)std::max<long>(1, std::min<long>(mpa_cdiv(max_size, 1024), 512)), (unsigned)ntensors);
-  hipLaunchKernelGGL(adamw_kernel, grid, dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, sizes, (float)lr,
+  MPA_LAUNCH(adamw_kernel, grid, dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, sizes, (float)lr,
                      (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)bc1, (float)sqrt(bc2));
   return mpa_launch_status();
 }

@@ -174,7 +174,7 @@ int mpa_maxpool2d_fwd(const float* x, float* y, int32_t* idx, int B, int C, int 
   const int OH = (H + 2 * ph - kh) / sh + 1, OW = (W + 2 * pw - kw) / sw + 1;
   if (OH <= 0 || OW <= 0) return MPA_ERR_ARG;
   const long planes = (long)B * C;
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(blocks_for(planes * OH * OW)), dim3(256), 0, (hipStream_t)stream, x, y, idx,
+  MPA_LAUNCH(maxpool_fwd_kernel, dim3(blocks_for(planes * OH * OW)), dim3(256), 0, (hipStream_t)stream, x, y, idx,
                      planes, H, W, OH, OW, kh, kw, sh, sw, ph, pw);
   return mpa_launch_status();
 }
@@ -184,7 +184,7 @@ int mpa_maxpool2d_bwd(const float* dy, const int32_t* idx, float* dx, int B, int
   if (!dy || !idx || !dx) return MPA_ERR_ARG;
   const int OH = (H + 2 * ph - kh) / sh + 1, OW = (W + 2 * pw - kw) / sw + 1;
   const long planes = (long)B * C;
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks_for(planes * H * W)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx,
+  MPA_LAUNCH(maxpool_bwd_kernel, dim3(blocks_for(planes * H * W)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx,
                      planes, H, W, OH, OW, kh, kw, sh, sw, ph, pw);
   return mpa_launch_status();
 }
@@ -192,7 +192,7 @@ int mpa_maxpool2d_bwd(const float* dy, const int32_t* idx, float* dx, int B, int
 int mpa_upcat_fwd(const float* x1, const float* skip, float* out, int B, int C1, int H1, int W1, int Cs, int Hs, int Ws,
                   void* stream) {
   if (!x1 || !skip || !out || Hs < 2 * H1 || Ws < 2 * W1) return MPA_ERR_ARG;
-  hipLaunchKernelGGL(upcat_fwd_kernel, dim3(blocks_for((long)B * (Cs + C1) * Hs * Ws)), dim3(256), 0, (hipStream_t)stream, x1,
+  MPA_LAUNCH(upcat_fwd_kernel, dim3(blocks_for((long)B * (Cs + C1) * Hs * Ws)), dim3(256), 0, (hipStream_t)stream, x1,
                      skip, out, B, C1, H1, W1, Cs, Hs, Ws);
   return mpa_launch_status();
 }
@@ -201,7 +201,7 @@ int mpa_upcat_bwd(const float* dout, float* dx1, float* dskip, int B, int C1, in
                   void* stream) {
   if (!dout || !dx1 || !dskip) return MPA_ERR_ARG;
   const long n = (long)B * Cs * Hs * Ws + (long)B * C1 * H1 * W1;
-  hipLaunchKernelGGL(upcat_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, dout, dx1, dskip, B, C1, H1, W1,
+  MPA_LAUNCH(upcat_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, dout, dx1, dskip, B, C1, H1, W1,
                      Cs, Hs, Ws);
   return mpa_launch_status();
 }

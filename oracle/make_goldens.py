@@ -122,14 +122,24 @@ def run_case64(cfg_name, B, T, train_step, out):
             if isinstance(m, torch.nn.Dropout):
                 m.p = 0.0
         model.train()
-        res = model(x)
-        loss = _loss(res, y, torch.nn.BCELoss(reduction="mean"), torch.nn.CrossEntropyLoss())
-        loss.backward()
-        out["train.loss64"] = np.array(loss.item())
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+        losses = []
+        for step in range(3):
+            res = model(x)
+            loss = _loss(res, y, torch.nn.BCELoss(reduction="mean"), torch.nn.CrossEntropyLoss())
+            opt.zero_grad()
+            loss.backward()
+            if step == 0:
+                out["train.loss64"] = np.array(loss.item())
+                for k, p in model.named_parameters():
+                    out[f"grad64.{k}.norm"] = np.array(p.grad.norm().item())
+                    out[f"grad64.{k}.absmax"] = np.array(p.grad.abs().max().item())
+                    out[f"grad64.{k}.samples"] = p.grad.numpy().ravel()[sample_idx(p.grad.numel(), 16)]
+            opt.step()
+            losses.append(loss.item())
+        out["train.losses64"] = np.array(losses)          # the fp64 trajectory: |losses - losses64| is fp32 chaos
         for k, p in model.named_parameters():
-            out[f"grad64.{k}.norm"] = np.array(p.grad.norm().item())
-            out[f"grad64.{k}.absmax"] = np.array(p.grad.abs().max().item())
-            out[f"grad64.{k}.samples"] = p.grad.numpy().ravel()[sample_idx(p.grad.numel(), 16)]
+            out[f"p3_64.{k}"] = np.array([p.detach().sum().item(), p.detach().norm().item()])
 
 
 def run_case(cfg_name, B, T, train_step):
