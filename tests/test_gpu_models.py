@@ -164,8 +164,7 @@ def test_train_step_matches_reference_goldens(dev, case):
         dev = np.abs(np.array(losses) - g["train.losses64"])
         assert (dev[stable] <= 4.0 * chaos[stable] + 1e-3 * max(1.0, abs(ref_losses[0]))).all(), (losses, list(ref_losses))
         if not stable.all():
-            return, \
-            (losses, list(ref_losses), list(g["train.losses64"]))
+            return
     else:
         assert np.abs(np.array(losses) - ref_losses).max() < 5e-2 * max(1.0, abs(ref_losses[0]))
     for k, p in model.named_parameters():
