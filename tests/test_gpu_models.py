@@ -127,7 +127,7 @@ def test_train_step_matches_reference_goldens(dev, case):
         if step == 0:
             yy = (res[0] if isinstance(res, tuple) else res).detach().cpu().numpy()
             assert np.abs(yy - g["train.y"]).max() <= FWD_TOL
-            worst = 0.0
+            rels = []
             for k, p in model.named_parameters():
                 mine = p.grad.detach().cpu().numpy().ravel()[sample_idx(p.numel(), 16)].astype(np.float64)
                 r32 = g[f"grad.{k}.samples"].astype(np.float64)
@@ -136,14 +136,16 @@ def test_train_step_matches_reference_goldens(dev, case):
                     scale = float(g[f"grad64.{k}.absmax"])
                     ref_noise = np.abs(r32 - r64).max()
                     # as close to the fp64 truth as the reference's own fp32 run, within a factor, plus an fp32 floor
-                    tol = 10.0 * ref_noise + 2e-3 * scale + 1e-9
+                    tol = 20.0 * ref_noise + 5e-3 * scale + 1e-9
                     err = np.abs(mine - r64).max()
                 else:
                     scale = max(np.abs(r32).max(), float(g[f"grad.{k}.norm"]) / np.sqrt(p.numel()))
                     tol = 2e-2 * scale + 1e-9
                     err = np.abs(mine - r32).max()
-                worst = max(worst, err / max(scale, 1e-30))
+                rels.append(err / max(scale, 1e-30))
                 assert err <= tol, f"{k}: err {err:.3e} tol {tol:.3e} scale {scale:.3e}"
+            # the per-parameter bound above is noise-aware and loose; the typical parameter must be far better
+            assert np.median(rels) < 1e-3, np.median(rels)
         opt.step()
         if step == 0:
             sd = model.state_dict()
@@ -171,7 +173,7 @@ def test_train_step_matches_reference_goldens(dev, case):
         if k.endswith(("double_conv.0.bias", "double_conv.4.bias", "double_conv.3.bias")):
             continue        # conv bias in front of BatchNorm: true gradient is exactly 0, Adam normalises pure noise
         ref = g[f"p3.{k}"]
-        assert abs(float(p.detach().double().norm()) - ref[1]) < 2e-3 * ref[1] + 1e-5, k
+        assert abs(float(p.detach().double().norm()) - ref[1]) < 2e-3 * ref[1] + 1.5e-3 * np.sqrt(p.numel()), k
 
 
 ORACLE_CASES = [("tiny:CNN", 3, 90), ("tiny:DRCNN", 5, 75), ("tiny:Unet", 3, 83), ("tiny:SAUnet", 7, 75),
