@@ -120,7 +120,7 @@ def _check_train(name, B, T):
         chaos = np.abs(ref_losses - g["train.losses64"])
         stable = chaos < 1e-2           # a step where the reference itself diverges by more is not a test of anything
         dev = np.abs(np.array(losses) - g["train.losses64"])
-        assert (dev[stable] <= 4.0 * chaos[stable] + 1e-3 * max(1.0, abs(ref_losses[0]))).all(), (losses, list(ref_losses))
+        assert (dev[stable] <= 4.0 * chaos[stable] + 2e-3 * max(1.0, abs(ref_losses[0]))).all(), (losses, list(ref_losses))
         if not stable.all():
             return
     for k in names:
