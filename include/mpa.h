@@ -57,6 +57,8 @@ int mpa_conv2d_fwd(const mpa_conv_desc* d, const float* x, const float* w_packed
                    float* y, int act, float slope, void* stream);
 /* dx = conv_transpose(dy, w)  (w_packed from mode 1) */
 int mpa_conv2d_bwd_data(const mpa_conv_desc* d, const float* dy, const float* w_packed, float* dx, void* stream);
+/* human-readable tiling chosen for fwd (mode 0), bwd-data (1), bwd-weight (2) -- diagnostics / DESIGN.md tables */
+int mpa_conv2d_describe_plan(const mpa_conv_desc* d, int mode, char* buf, int buflen);
 /* dw = sum_b,y,x dy * x ; db = sum dy (db may be NULL).  workspace bytes from the helper. */
 int64_t mpa_conv2d_bwd_weight_workspace(const mpa_conv_desc* d);
 int mpa_conv2d_bwd_weight(const mpa_conv_desc* d, const float* x, const float* dy, float* dw, float* db,

@@ -42,6 +42,7 @@ SIGNATURES = {
     "mpa_conv2d_pack": (c_int, [_D, c_int, _P, _P, _P]),
     "mpa_conv2d_fwd": (c_int, [_D, _P, _P, _P, _P, c_int, c_float, _P]),
     "mpa_conv2d_bwd_data": (c_int, [_D, _P, _P, _P, _P]),
+    "mpa_conv2d_describe_plan": (c_int, [_D, c_int, ctypes.c_char_p, c_int]),
     "mpa_conv2d_bwd_weight_workspace": (c_int64, [_D]),
     "mpa_conv2d_bwd_weight": (c_int, [_D, _P, _P, _P, _P, _P, c_int64, _P]),
     "mpa_layernorm_cf_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),

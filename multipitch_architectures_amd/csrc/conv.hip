@@ -18,6 +18,7 @@
 #include "mpa_common.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 
 namespace {
 
@@ -51,8 +52,9 @@ FwdPlan plan_fwd(int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw
   const int COTP = (COT % 32 == 0) ? COT + 16 : COT;   // filter-slab pitch == 16 (mod 32): conflict-free A reads
   const int cin4 = (int)mpa_cdiv(Cin, 4) * 4;
   double bestcost = 1e300;
-  const int pbs[4] = {1, 2, 4, 6};
-  for (int pi = 0; pi < 4; ++pi) {
+  const int pbs[6] = {1, 2, 4, 6, 8, 12};
+  for (int pi = 0; pi < 6; ++pi) {
+    if ((pbs[pi] == 12 && NB > 2) || (pbs[pi] == 8 && NB > 4)) continue;   // accumulator budget
     const int PB = pbs[pi], P = PB * 64;
     for (int TH = 1; TH <= std::min(OH, P); ++TH) {
       const int TWmax = std::min(OW, P / TH);
@@ -101,24 +103,29 @@ __device__ __forceinline__ void fast_divmod(int idx, int d, float inv, int& q, i
 __device__ __forceinline__ void stage_window(float* __restrict__ dst, const float* __restrict__ src, int tid, int nch,
                                              int nrows, int ncols, int chp, int lw, int c0, int y0, int x0, int C, int H,
                                              int W, int xlim) {
+  // element idx = tid + 256*k walks (ch, iy, ix) incrementally: no per-element division
   const int total = nch * nrows * ncols;
-  const float inv_c = 1.0f / (float)ncols, inv_r = 1.0f / (float)nrows;
+  int row, ix, ch, iy;
+  fast_divmod(tid, ncols, 1.0f / (float)ncols, row, ix);
+  fast_divmod(row, nrows, 1.0f / (float)nrows, ch, iy);
+  int dq, dr;
+  fast_divmod(256, ncols, 1.0f / (float)ncols, dq, dr);
   for (int base = tid; base < total; base += 256 * 4) {
     float v[4];
     int o[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int idx = base + u * 256;
       v[u] = 0.f;
       o[u] = -1;
-      if (idx < total) {
-        int row, ix, ch, iy;
-        fast_divmod(idx, ncols, inv_c, row, ix);
-        fast_divmod(row, nrows, inv_r, ch, iy);
+      if (base + u * 256 < total) {
         const int gc = c0 + ch, gy = y0 + iy, gx = x0 + ix;
         o[u] = ch * chp + iy * lw + ix;
         if (gc < C && gy >= 0 && gy < H && gx >= 0 && gx < xlim) v[u] = src[((long)gc * H + gy) * W + gx];
       }
+      ix += dr;
+      iy += dq;
+      if (ix >= ncols) { ix -= ncols; iy += 1; }
+      while (iy >= nrows) { iy -= nrows; ch += 1; }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -259,6 +266,12 @@ int launch_fwd_nb(const FwdPlan& pl, const ConvFwdParams& p, hipStream_t s) {
     case 2: MPA_LAUNCH((conv_fwd_kernel<NB, 2>), grid, dim3(256), pl.lds_bytes, s, p); break;
     case 4: MPA_LAUNCH((conv_fwd_kernel<NB, 4>), grid, dim3(256), pl.lds_bytes, s, p); break;
     case 6: MPA_LAUNCH((conv_fwd_kernel<NB, 6>), grid, dim3(256), pl.lds_bytes, s, p); break;
+    case 8:
+      if constexpr (NB <= 4) { MPA_LAUNCH((conv_fwd_kernel<NB, 8>), grid, dim3(256), pl.lds_bytes, s, p); break; }
+      return MPA_ERR_UNSUPPORTED;
+    case 12:
+      if constexpr (NB <= 2) { MPA_LAUNCH((conv_fwd_kernel<NB, 12>), grid, dim3(256), pl.lds_bytes, s, p); break; }
+      return MPA_ERR_UNSUPPORTED;
     default: return MPA_ERR_UNSUPPORTED;
   }
   return mpa_launch_status();
@@ -344,58 +357,113 @@ struct WgPlan {
 };
 
 WgPlan plan_wgrad(const mpa_conv_desc* d) {
-  WgPlan pl{};
-  pl.ok = false;
+  WgPlan best{};
+  best.ok = false;
   const int OH = (d->H + 2 * d->ph - d->kh) / d->sh + 1, OW = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
-  if (OH <= 0 || OW <= 0) return pl;
+  if (OH <= 0 || OW <= 0) return best;
   const int khkw = d->kh * d->kw;
-  pl.OH = OH; pl.OW = OW;
-  pl.Ntot = d->Cin * khkw;
-  {
-    const int nbs[4] = {1, 2, 4, 5}, ntw[4] = {16, 8, 6, 6};
-    long bestpad = -1;
-    for (int i = 0; i < 4; ++i) {
-      const long pad = mpa_cdiv(d->Cout, nbs[i] * 16) * nbs[i] * 16;
-      if (bestpad < 0 || pad < bestpad || (pad == bestpad && nbs[i] > pl.NBC)) { bestpad = pad; pl.NBC = nbs[i]; pl.NTW = ntw[i]; }
-    }
-  }
-  pl.COT = pl.NBC * 16;
-  pl.coTiles = (int)mpa_cdiv(d->Cout, pl.COT);
-  pl.nPerBlock = 4 * pl.NTW * 16;
-  pl.nTiles = (int)mpa_cdiv(pl.Ntot, pl.nPerBlock);
-  pl.XCH = std::min(d->Cin, (pl.nPerBlock + khkw - 2) / khkw + 1);
-  // pixel tile: full-width rows when they fit in LDS, else split the width
+  const int Ntot = d->Cin * khkw;
+  // wave tile variants (cout blocks x tap blocks); many tap blocks per wave = few dY floats staged per MFMA
+  const int var_nbc[5] = {1, 2, 2, 4, 5}, var_ntw[5] = {16, 8, 16, 6, 6};
   double bestcost = 1e300;
-  for (int txn = 1; txn <= OW; ++txn) {
-    const int TW = (int)mpa_cdiv(OW, txn);
-    const int DP = (int)mpa_cdiv(TW, 4) * 4;
-    const int IW = (DP - 1) * d->sw + d->kw;
-    const int LW = IW | 1;
-    for (int TH = std::min(OH, 64); TH >= 1; --TH) {
-      const int IH = (TH - 1) * d->sh + d->kh;
-      const int XCHP = IH * LW;
-      const int DCP = round_mod(TH * DP, 32, 2);
-      const size_t lds = (size_t)(pl.XCH * XCHP + pl.COT * DCP) * 4;
-      if (lds > 64 * 1024) continue;
-      const int ty = (int)mpa_cdiv(OH, TH);
-      // MFMA work ~ padded pixels; staging ~ tile bytes
-      double cost = (double)ty * txn * (TH * DP * (double)(pl.NBC * pl.NTW) * 4 * 8 + 0.5 * (lds / 4));
-      if (cost < bestcost) {
-        bestcost = cost;
-        pl.TH = TH; pl.TW = TW; pl.DP = DP; pl.tilesY = ty; pl.tilesX = txn; pl.IH = IH; pl.IW = IW; pl.LW = LW;
-        pl.XCHP = XCHP; pl.DCP = DCP; pl.lds_bytes = lds; pl.ok = true;
+  for (int v = 0; v < 5; ++v) {
+    WgPlan pl{};
+    pl.OH = OH; pl.OW = OW; pl.Ntot = Ntot;
+    pl.NBC = var_nbc[v]; pl.NTW = var_ntw[v];
+    pl.COT = pl.NBC * 16;
+    pl.coTiles = (int)mpa_cdiv(d->Cout, pl.COT);
+    pl.nPerBlock = 4 * pl.NTW * 16;
+    pl.nTiles = (int)mpa_cdiv(Ntot, pl.nPerBlock);
+    pl.XCH = std::min(d->Cin, (pl.nPerBlock + khkw - 2) / khkw + 1);
+    const double pad_eff = ((double)pl.coTiles * pl.COT / d->Cout) * ((double)pl.nTiles * pl.nPerBlock / Ntot);
+    for (int txn = 1; txn <= std::min(OW, 64); ++txn) {
+      const int TW = (int)mpa_cdiv(OW, txn);
+      const int DP = (int)mpa_cdiv(TW, 4) * 4;
+      const int IW = (DP - 1) * d->sw + d->kw;
+      const int LW = IW | 1;
+      for (int TH = std::min(OH, 64); TH >= 1; --TH) {
+        const int IH = (TH - 1) * d->sh + d->kh;
+        const int XCHP = IH * LW;
+        const int DCP = round_mod(TH * DP, 32, 2);
+        const long floats = mpa_cdiv((long)pl.XCH * XCHP, 64) * 64 + mpa_cdiv((long)pl.COT * DCP, 64) * 64;
+        if (floats * 4 > 64 * 1024) continue;
+        const int ty = (int)mpa_cdiv(OH, TH);
+        // cycles per tile: MFMA issue (per wave) + un-overlapped share of the staging (~100 cycles per float per thread)
+        const double mfma = (double)TH * (DP / 4) * pl.NBC * pl.NTW * 32.0;
+        const double stage = (double)(pl.XCH * IH * IW + pl.COT * TH * DP) / 256.0 * 100.0;
+        const double cost = (double)ty * txn * (mfma + 0.6 * stage + 600.0) * pad_eff;
+        if (cost < bestcost) {
+          bestcost = cost;
+          best = pl;
+          best.TH = TH; best.TW = TW; best.DP = DP; best.tilesY = ty; best.tilesX = txn; best.IH = IH; best.IW = IW;
+          best.LW = LW; best.XCHP = XCHP; best.DCP = DCP; best.lds_bytes = (size_t)floats * 4; best.ok = true;
+        }
+        break;   // largest TH that fits for this TW
       }
-      break;   // largest TH that fits for this TW
     }
-    if (txn > 8 && pl.ok) break;
   }
-  if (!pl.ok) return pl;
-  const long totalTiles = (long)d->B * pl.tilesY * pl.tilesX;
-  long S = (256L * 3) / ((long)pl.nTiles * pl.coTiles);
-  if (S < 1) S = 1;
+  if (!best.ok) return best;
+  // split the (image, tile) loop over S blocks so that the grid is a whole number of resident waves of workgroups
+  const long totalTiles = (long)d->B * best.tilesY * best.tilesX;
+  const long per_cu = std::max<long>(1, std::min<long>(2, (160 * 1024) / (long)best.lds_bytes));
+  const long slots = 256 * per_cu;
+  const long groups = (long)best.nTiles * best.coTiles;
+  long S = std::max<long>(1, (2 * slots) / groups);
+  if (groups * S < slots && S < totalTiles) S = mpa_cdiv(slots, groups);
   if (S > totalTiles) S = totalTiles;
-  pl.S = (int)S;
-  return pl;
+  if (S > 1024) S = 1024;
+  best.S = (int)S;
+  return best;
+}
+
+// LDS-DMA staging (global_load_lds_dword): every LDS word of the image is fetched straight from global memory
+// -- or from a zero word when it lies outside the tensor -- with no VGPR round trip, so a whole tile (~60 loads per
+// lane) is in flight at once instead of being paid for in dependent batches.
+__device__ float mpa_zero_src[64];
+
+__device__ __forceinline__ void glds_word(const float* src, float* lds_dst_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_dst_wave_base, 4, 0, 0);
+}
+
+// image [nch][nrows][lw] (channel pitch nrows*lw exactly), padded to a multiple of 64 words (`total64`)
+__device__ __forceinline__ void glds_stage_x(float* __restrict__ dst, const float* __restrict__ src, int lane, int wave,
+                                             int nch, int nrows, int ncols, int lw, int total64, int c0, int y0, int x0,
+                                             int C, int H, int W) {
+  int ch, iy, ix, row, dq, dr;
+  fast_divmod(wave * 64 + lane, lw, 1.0f / (float)lw, row, ix);
+  fast_divmod(row, nrows, 1.0f / (float)nrows, ch, iy);
+  fast_divmod(256, lw, 1.0f / (float)lw, dq, dr);
+  const float* zsrc = &mpa_zero_src[lane];
+  for (int base = wave * 64; base < total64; base += 256) {
+    const int gc = c0 + ch, gy = y0 + iy, gx = x0 + ix;
+    const bool ok = ch < nch && ix < ncols && gc < C && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    glds_word(ok ? src + ((long)gc * H + gy) * W + gx : zsrc, dst + base);
+    ix += dr;
+    iy += dq;
+    if (ix >= lw) { ix -= lw; iy += 1; }
+    while (iy >= nrows) { iy -= nrows; ch += 1; }
+  }
+}
+
+// image [nco][dcp] with the first th*dp words of a row holding (py, px); padded to `total64`
+__device__ __forceinline__ void glds_stage_dy(float* __restrict__ dst, const float* __restrict__ src, int lane, int wave,
+                                              int nco, int th, int dp, int dcp, int total64, int c0, int y0, int x0, int C,
+                                              int OH, int OW, int xlim) {
+  int co, r;
+  fast_divmod(wave * 64 + lane, dcp, 1.0f / (float)dcp, co, r);
+  const float inv_dp = 1.0f / (float)dp;
+  const float* zsrc = &mpa_zero_src[lane];
+  const int npx = th * dp;
+  for (int base = wave * 64; base < total64; base += 256) {
+    int py, px;
+    fast_divmod(r, dp, inv_dp, py, px);
+    const int gc = c0 + co, oy = y0 + py, ox = x0 + px;
+    const bool ok = co < nco && r < npx && gc < C && oy < OH && ox < xlim;
+    glds_word(ok ? src + ((long)gc * OH + oy) * OW + ox : zsrc, dst + base);
+    r += 256;
+    while (r >= dcp) { r -= dcp; co += 1; }
+  }
 }
 
 struct WgParams {
@@ -404,6 +472,7 @@ struct WgParams {
   float* ws;
   int B, Cin, H, W, Cout, OH, OW, kh, kw, sh, sw, ph, pw;
   int COT, nPerBlock, Ntot, XCH, TH, TW, DP, tilesY, tilesX, IH, IW, LW, XCHP, DCP, S;
+  int TX64, TD64;   // LDS words of the X / dY images, each rounded up to a multiple of 64
   int with_bias;   // workspace rows carry one extra column: sum over pixels of dY (the bias gradient)
 };
 
@@ -411,7 +480,7 @@ template <int NBC, int NTW>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lds_x = lds;
-  float* lds_dy = lds + p.XCH * p.XCHP;
+  float* lds_dy = lds + p.TX64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kq = lane >> 4, l16 = lane & 15;
   const int split = blockIdx.x, ntile = blockIdx.y, cot = blockIdx.z;
@@ -447,11 +516,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgParams p) {
     const int oy0 = ty * p.TH, ox0 = tx * p.TW;
     const int iy0 = oy0 * p.sh - p.ph, ix0 = ox0 * p.sw - p.pw;
     __syncthreads();
-    stage_window(lds_x, p.x + (long)b * p.Cin * p.H * p.W, tid, p.XCH, p.IH, p.IW, p.XCHP, p.LW, ci_first, iy0, ix0,
-                 p.Cin, p.H, p.W, p.W);
+    glds_stage_x(lds_x, p.x + (long)b * p.Cin * p.H * p.W, lane, wave, p.XCH, p.IH, p.IW, p.LW, p.TX64, ci_first, iy0, ix0,
+                 p.Cin, p.H, p.W);
     // dY tile: columns >= TW belong to the neighbouring tile -> clip the readable width at ox0+TW
-    stage_window(lds_dy, p.dy + (long)b * p.Cout * p.OH * p.OW, tid, p.COT, p.TH, p.DP, p.DCP, p.DP, cot * p.COT, oy0,
-                 ox0, p.Cout, p.OH, p.OW, min(p.OW, ox0 + p.TW));
+    glds_stage_dy(lds_dy, p.dy + (long)b * p.Cout * p.OH * p.OW, lane, wave, p.COT, p.TH, p.DP, p.DCP, p.TD64, cot * p.COT,
+                  oy0, ox0, p.Cout, p.OH, p.OW, min(p.OW, ox0 + p.TW));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (do_bias) {
       // 2 threads per cout (COT <= 80 < 128), each summing half of the tile's pixels (zero-filled outside the image)
@@ -501,6 +571,185 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgParams p) {
     const int co = cot * p.COT + (tid >> 1);
     if ((tid & 1) == 0 && (tid >> 1) < p.COT && co < p.Cout) out[(long)co * NtotP + p.Ntot] = bsum;
   }
+}
+
+
+// ------------------------------------------------------------------------------------------------ backward-weight, 15x15
+// 88 % of the model's conv FLOPs sit in 15x15 stride-1 filters (inc, down1, upconv4; DRCNN prefilters), so their
+// weight gradient gets a dedicated kernel: the MFMA N dimension is the 15 dx taps (padded to 16) of one (ci, dy) row
+// and the X tile has a fixed LDS row pitch of 128 words, so every B-operand read is `base + immediate` (dy*512 B)
+// -- one address VGPR for 15 reads instead of a running pointer per tap block.
+//   wave tile: NBC cout blocks x CIW input channels x 15 dy  (acc = NBC*CIW*15 tiles of 16x16)
+//   block    : 4 waves = 4*CIW input channels sharing one dY tile of NBC*16 couts
+constexpr int W15_PITCH = 128;
+
+struct Wg15Params {
+  const float* x;
+  const float* dy;
+  float* ws;
+  int B, Cin, H, W, Cout, OH, OW;
+  int COT, TH, TW, DP, tilesY, tilesX, IH, IW, DCP, S, Ntot, TX64, TD64;
+};
+
+template <int NBC, int CIW>
+__global__ __launch_bounds__(256) void conv_wgrad15_kernel(const Wg15Params p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* lds_x = lds;
+  float* lds_dy = lds + p.TX64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kq = lane >> 4, l16 = lane & 15;
+  const int split = blockIdx.x, cig = blockIdx.y, cot = blockIdx.z;
+  const int ci_first = cig * 4 * CIW;
+  const int xchp = p.IH * W15_PITCH;
+  const int NtotP = p.Ntot + 1;
+  const bool do_bias = cig == 0;
+  float bsum = 0.f;
+  f32x4 acc[NBC][CIW][15];
+#pragma unroll
+  for (int a = 0; a < NBC; ++a)
+#pragma unroll
+    for (int c = 0; c < CIW; ++c)
+#pragma unroll
+      for (int t = 0; t < 15; ++t) acc[a][c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int tilesPerImg = p.tilesY * p.tilesX;
+  const long totalTiles = (long)p.B * tilesPerImg;
+  const float* bbase = lds_x + wave * CIW * xchp + kq + l16;
+  const float* abase = lds_dy + l16 * p.DCP + kq;
+  for (long tile = split; tile < totalTiles; tile += p.S) {
+    const int b = (int)(tile / tilesPerImg);
+    const int tr = (int)(tile - (long)b * tilesPerImg);
+    const int ty = tr / p.tilesX, tx = tr - ty * p.tilesX;
+    const int oy0 = ty * p.TH, ox0 = tx * p.TW;
+    __syncthreads();
+    glds_stage_x(lds_x, p.x + (long)b * p.Cin * p.H * p.W, lane, wave, 4 * CIW, p.IH, p.IW, W15_PITCH, p.TX64, ci_first,
+                 oy0 - 7, ox0 - 7, p.Cin, p.H, p.W);
+    glds_stage_dy(lds_dy, p.dy + (long)b * p.Cout * p.OH * p.OW, lane, wave, p.COT, p.TH, p.DP, p.DCP, p.TD64, cot * p.COT,
+                  oy0, ox0, p.Cout, p.OH, p.OW, min(p.OW, ox0 + p.TW));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (do_bias) {
+      const int co = tid >> 1, part = tid & 1;
+      if (co < p.COT) {
+        const float* row = lds_dy + co * p.DCP;
+        const int npx = p.TH * p.DP;
+        float s = 0.f;
+        for (int i = part; i < npx; i += 2) s += row[i];
+        bsum += s;
+      }
+    }
+    for (int py = 0; py < p.TH; ++py) {
+      const float* ap = abase + py * p.DP;
+      const float* bp = bbase + py * W15_PITCH;
+      // two explicit operand register sets: the LDS reads of step k+1 are issued before the MFMAs of step k
+      float a0[NBC], b0[CIW][15], a1[NBC], b1[CIW][15];
+#define W15_LOAD(A, Bv, PX)                                                                \
+  {                                                                                        \
+    _Pragma("unroll") for (int cb = 0; cb < NBC; ++cb) A[cb] = ap[cb * 16 * p.DCP + (PX)]; \
+    _Pragma("unroll") for (int c = 0; c < CIW; ++c)                                        \
+      _Pragma("unroll") for (int t = 0; t < 15; ++t) Bv[c][t] = bp[c * xchp + t * W15_PITCH + (PX)]; \
+  }
+#define W15_MMA(A, Bv)                                                                      \
+  {                                                                                         \
+    _Pragma("unroll") for (int c = 0; c < CIW; ++c)                                         \
+      _Pragma("unroll") for (int t = 0; t < 15; ++t)                                        \
+        _Pragma("unroll") for (int cb = 0; cb < NBC; ++cb)                                  \
+          acc[cb][c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[cb], Bv[c][t], acc[cb][c][t], 0, 0, 0); \
+  }
+      W15_LOAD(a0, b0, 0)
+      for (int px0 = 0; px0 < p.DP; px0 += 8) {
+        const int p1 = px0 + 4 < p.DP ? px0 + 4 : px0;
+        W15_LOAD(a1, b1, p1)
+        __builtin_amdgcn_sched_barrier(0);
+        W15_MMA(a0, b0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (px0 + 4 < p.DP) {
+          const int p2 = px0 + 8 < p.DP ? px0 + 8 : px0 + 4;
+          W15_LOAD(a0, b0, p2)
+          __builtin_amdgcn_sched_barrier(0);
+          W15_MMA(a1, b1)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#undef W15_LOAD
+#undef W15_MMA
+    }
+  }
+  // D[row = cout (kq*4+r)][col = dx (l16)]
+  float* out = p.ws + (long)split * p.Cout * NtotP;
+  if (l16 < 15) {
+#pragma unroll
+    for (int c = 0; c < CIW; ++c) {
+      const int ci = ci_first + wave * CIW + c;
+      if (ci >= p.Cin) continue;
+#pragma unroll
+      for (int t = 0; t < 15; ++t)
+#pragma unroll
+        for (int cb = 0; cb < NBC; ++cb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int co = cot * p.COT + cb * 16 + kq * 4 + r;
+            if (co < p.Cout) out[(long)co * NtotP + ci * 225 + t * 15 + l16] = acc[cb][c][t][r];
+          }
+    }
+  }
+  if (do_bias) {
+    bsum += __shfl_xor(bsum, 1, 64);
+    const int co = cot * p.COT + (tid >> 1);
+    if ((tid & 1) == 0 && (tid >> 1) < p.COT && co < p.Cout) out[(long)co * NtotP + p.Ntot] = bsum;
+  }
+}
+
+struct Wg15Plan {
+  int NBC, CIW, COT, coTiles, ciGroups, TH, TW, DP, tilesY, tilesX, IH, IW, DCP, S, TX64, TD64;
+  size_t lds_bytes;
+  bool ok;
+};
+
+Wg15Plan plan_wgrad15(const mpa_conv_desc* d) {
+  Wg15Plan pl{};
+  pl.ok = false;
+  if (d->kh != 15 || d->kw != 15 || d->sh != 1 || d->sw != 1 || d->ph != 7 || d->pw != 7) return pl;
+  const int OH = d->H, OW = d->W;
+  pl.NBC = d->Cout <= 16 ? 1 : 2;
+  pl.CIW = 1;
+  pl.COT = pl.NBC * 16;
+  pl.coTiles = (int)mpa_cdiv(d->Cout, pl.COT);
+  pl.ciGroups = (int)mpa_cdiv(d->Cin, 4 * pl.CIW);
+  const long budget = 78 * 1024;      // two workgroups per CU (160 KiB LDS)
+  double bestcost = 1e300;
+  for (int txn = 1; txn <= OW; ++txn) {
+    const int TW = (int)mpa_cdiv(OW, txn);
+    const int DP = (int)mpa_cdiv(TW, 4) * 4;
+    const int IW = DP + 14;
+    if (IW > W15_PITCH) continue;
+    for (int TH = std::min(OH, 32); TH >= 1; --TH) {
+      const int IH = TH + 14;
+      const int DCP = round_mod(TH * DP, 32, 2);
+      const long tx64 = mpa_cdiv((long)4 * pl.CIW * IH * W15_PITCH, 64) * 64, td64 = mpa_cdiv((long)pl.COT * DCP, 64) * 64;
+      if ((tx64 + td64) * 4 > budget) continue;
+      const int ty = (int)mpa_cdiv(OH, TH);
+      const double mfma = (double)TH * (DP / 4) * pl.NBC * pl.CIW * 15 * 32.0;
+      const double stage = (double)(tx64 + td64) / 64.0 * 80.0 / 4.0;      // LDS-DMA issue cost per wave
+      const double cost = (double)ty * txn * (mfma + stage + 3000.0);
+      if (cost < bestcost) {
+        bestcost = cost;
+        pl.TH = TH; pl.TW = TW; pl.DP = DP; pl.tilesY = ty; pl.tilesX = txn; pl.IH = IH; pl.IW = IW; pl.DCP = DCP;
+        pl.TX64 = (int)tx64; pl.TD64 = (int)td64; pl.lds_bytes = (size_t)(tx64 + td64) * 4; pl.ok = true;
+      }
+      break;
+    }
+    if (txn >= 8 && pl.ok) break;
+  }
+  if (!pl.ok) return pl;
+  const long totalTiles = (long)d->B * pl.tilesY * pl.tilesX;
+  const long per_cu = std::max<long>(1, std::min<long>(2, (160 * 1024) / (long)pl.lds_bytes));
+  const long slots = 256 * per_cu, groups = (long)pl.ciGroups * pl.coTiles;
+  long S = std::max<long>(1, (2 * slots) / groups);
+  if (S > totalTiles) S = totalTiles;
+  if (S > 1024) S = 1024;
+  pl.S = (int)S;
+  return pl;
 }
 
 // ws [S][Cout][NtotP] -> dw [Cout][Ntot] (+ db [Cout] from the extra column)
@@ -599,8 +848,39 @@ int mpa_conv2d_bwd_data(const mpa_conv_desc* d, const float* dy, const float* w_
                        MPA_ACT_NONE, 0.f, inBS, inCS, d->W, d->sw, d->Cin, (hipStream_t)stream);
 }
 
+int mpa_conv2d_describe_plan(const mpa_conv_desc* d, int mode, char* buf, int buflen) {
+  if (!d || !buf || buflen <= 0) return MPA_ERR_ARG;
+  if (mode == 2) {
+    Wg15Plan q = plan_wgrad15(d);
+    if (q.ok) {
+      snprintf(buf, buflen, "wgrad15<%d,%d> COT=%d coTiles=%d ciGroups=%d tile=%dx%d (DP %d) tiles=%dx%d S=%d lds=%zuB", q.NBC,
+               q.CIW, q.COT, q.coTiles, q.ciGroups, q.TH, q.TW, q.DP, q.tilesY, q.tilesX, q.S, q.lds_bytes);
+      return MPA_OK;
+    }
+    WgPlan w = plan_wgrad(d);
+    if (!w.ok) return MPA_ERR_UNSUPPORTED;
+    snprintf(buf, buflen, "wgrad<%d,%d> COT=%d coTiles=%d nPerBlock=%d nTiles=%d XCH=%d tile=%dx%d (DP %d) tiles=%dx%d S=%d lds=%zuB",
+             w.NBC, w.NTW, w.COT, w.coTiles, w.nPerBlock, w.nTiles, w.XCH, w.TH, w.TW, w.DP, w.tilesY, w.tilesX, w.S,
+             w.lds_bytes);
+    return MPA_OK;
+  }
+  FwdPlan f;
+  if (mode == 0) f = plan_fwd(d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw);
+  else {
+    BwdDataGeom g = bwd_data_geom(d);
+    if (!g.ok) return MPA_ERR_UNSUPPORTED;
+    f = plan_fwd(g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw);
+  }
+  if (!f.ok) return MPA_ERR_UNSUPPORTED;
+  snprintf(buf, buflen, "fwd<%d,%d> COT=%d coTiles=%d CK=%d chunks=%d tile=%dx%d tiles=%dx%d halo=%dx%d LW=%d lds=%zuB", f.NB,
+           f.PB, f.COT, f.coTiles, f.CK, f.nChunks, f.TH, f.TW, f.tilesY, f.tilesX, f.IH, f.IW, f.LW, f.lds_bytes);
+  return MPA_OK;
+}
+
 int64_t mpa_conv2d_bwd_weight_workspace(const mpa_conv_desc* d) {
   if (!d) return MPA_ERR_ARG;
+  Wg15Plan p15 = plan_wgrad15(d);
+  if (p15.ok) return (int64_t)p15.S * d->Cout * (d->Cin * 225 + 1) * 4;
   WgPlan pl = plan_wgrad(d);
   if (!pl.ok) return MPA_ERR_UNSUPPORTED;
   return (int64_t)pl.S * d->Cout * (pl.Ntot + 1) * 4;
@@ -609,6 +889,33 @@ int64_t mpa_conv2d_bwd_weight_workspace(const mpa_conv_desc* d) {
 int mpa_conv2d_bwd_weight(const mpa_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
                           void* workspace, int64_t workspace_bytes, void* stream) {
   if (!d || !x || !dy || !dw || d->B <= 0) return MPA_ERR_ARG;
+  Wg15Plan p15 = plan_wgrad15(d);
+  if (p15.ok) {
+    const int Ntot = d->Cin * 225;
+    const int64_t need15 = (int64_t)p15.S * d->Cout * (Ntot + 1) * 4;
+    if (!workspace || workspace_bytes < need15) return MPA_ERR_WORKSPACE;
+    Wg15Params q{};
+    q.x = x; q.dy = dy; q.ws = (float*)workspace;
+    q.B = d->B; q.Cin = d->Cin; q.H = d->H; q.W = d->W; q.Cout = d->Cout; q.OH = d->H; q.OW = d->W;
+    q.COT = p15.COT; q.TH = p15.TH; q.TW = p15.TW; q.DP = p15.DP; q.tilesY = p15.tilesY; q.tilesX = p15.tilesX;
+    q.IH = p15.IH; q.IW = p15.IW; q.DCP = p15.DCP; q.S = p15.S; q.Ntot = Ntot; q.TX64 = p15.TX64; q.TD64 = p15.TD64;
+    hipStream_t s15 = (hipStream_t)stream;
+    dim3 grid15((unsigned)p15.S, (unsigned)p15.ciGroups, (unsigned)p15.coTiles);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)conv_wgrad15_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_wgrad15_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      attr_set = true;
+    }
+    if (p15.NBC == 1) MPA_LAUNCH((conv_wgrad15_kernel<1, 1>), grid15, dim3(256), p15.lds_bytes, s15, q);
+    else MPA_LAUNCH((conv_wgrad15_kernel<2, 1>), grid15, dim3(256), p15.lds_bytes, s15, q);
+    int rc15 = mpa_launch_status();
+    if (rc15) return rc15;
+    const long n15 = (long)d->Cout * (Ntot + 1);
+    MPA_LAUNCH(reduce_partials_kernel, dim3((unsigned)std::min<long>(mpa_cdiv(n15, 256), 2048)), dim3(256), 0, s15,
+               (const float*)workspace, dw, db, d->Cout, Ntot, Ntot + 1, p15.S);
+    return mpa_launch_status();
+  }
   WgPlan pl = plan_wgrad(d);
   if (!pl.ok) return MPA_ERR_UNSUPPORTED;
   const int64_t need = (int64_t)pl.S * d->Cout * (pl.Ntot + 1) * 4;
@@ -620,10 +927,13 @@ int mpa_conv2d_bwd_weight(const mpa_conv_desc* d, const float* x, const float* d
   p.COT = pl.COT; p.nPerBlock = pl.nPerBlock; p.Ntot = pl.Ntot; p.XCH = pl.XCH; p.TH = pl.TH; p.TW = pl.TW; p.DP = pl.DP;
   p.tilesY = pl.tilesY; p.tilesX = pl.tilesX; p.IH = pl.IH; p.IW = pl.IW; p.LW = pl.LW; p.XCHP = pl.XCHP; p.DCP = pl.DCP;
   p.S = pl.S;
+  p.TX64 = (int)(mpa_cdiv((long)pl.XCH * pl.XCHP, 64) * 64);
+  p.TD64 = (int)(mpa_cdiv((long)pl.COT * pl.DCP, 64) * 64);
   p.with_bias = 1;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)pl.S, (unsigned)pl.nTiles, (unsigned)pl.coTiles);
   if (pl.NBC == 1) MPA_LAUNCH((conv_wgrad_kernel<1, 16>), grid, dim3(256), pl.lds_bytes, s, p);
+  else if (pl.NBC == 2 && pl.NTW == 16) MPA_LAUNCH((conv_wgrad_kernel<2, 16>), grid, dim3(256), pl.lds_bytes, s, p);
   else if (pl.NBC == 2) MPA_LAUNCH((conv_wgrad_kernel<2, 8>), grid, dim3(256), pl.lds_bytes, s, p);
   else if (pl.NBC == 4) MPA_LAUNCH((conv_wgrad_kernel<4, 6>), grid, dim3(256), pl.lds_bytes, s, p);
   else MPA_LAUNCH((conv_wgrad_kernel<5, 6>), grid, dim3(256), pl.lds_bytes, s, p);
