@@ -19,12 +19,15 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 
 namespace {
 
 // ------------------------------------------------------------------------------------------------ planning
+constexpr long FWD_LDS_BUDGET = 78 * 1024;   // two workgroups per CU (160 KiB LDS)
+
 struct FwdPlan {
-  int NB, PB, TH, TW, tilesY, tilesX, CK, nChunks, IH, IW, LW, CHP, COT, COTP, coTiles, OH, OW;
+  int NB, PB, TH, TW, tilesY, tilesX, CK, nChunks, IH, IW, LW, CHP, COT, COTP, coTiles, OH, OW, quad;
   size_t lds_bytes;
   bool ok;
 };
@@ -68,21 +71,32 @@ FwdPlan plan_fwd(int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw
         const int ty = (int)mpa_cdiv(OH, TH);
         const int IH = (TH - 1) * sh + kh, IW = (TW - 1) * sw + kw;
         for (int lwi = 0; lwi < 2; ++lwi) {
-          // row pitch == TW (mod 32) keeps pixel blocks that wrap a row conflict-free; fall back to the tight pitch
-          int LW = (lwi == 0 && sw == 1 && kw - 1 <= 32) ? TW + 32 : (IW | 1);
+          // row pitch == TW (mod 32) keeps pixel blocks that wrap a row conflict-free; fall back to the tight pitch.
+          // 16-byte LDS-DMA staging (quad): stride 1, W % 4 == 0, pitch % 4 == 0 and 3 spare columns for the
+          // 4-aligned window origin.
+          int LW = (lwi == 0 && sw == 1 && kw - 1 <= 29) ? TW + 32 : (IW | 1);
           if (LW < IW) LW = IW | 1;
+          int quad = 0;
+          if (sw == 1 && W % 4 == 0) {
+            int lq = LW;
+            if (lq % 4 != 0 || lq < IW + 3) lq = (int)mpa_cdiv(std::max(LW, IW + 3), 4) * 4;
+            if (lwi == 1 || lq == LW) { LW = lq; quad = 1; }
+          }
           const int CHP = round_mod(IH * LW, 32, 16);
           int CK = 4;
           while (CK < 32 && CK < cin4 && kw * (CK / 4) < 15) CK *= 2;
-          while (CK > 4 && (size_t)(CK * CHP + kw * CK * COTP) * 4 > 64 * 1024) CK /= 2;
-          const size_t lds = (size_t)(CK * CHP + kw * CK * COTP) * 4;
-          if (lds > 64 * 1024) continue;
+          auto lds_words = [&](int ck) {
+            return mpa_cdiv((long)ck * CHP, 64) * 64 + 2 * (mpa_cdiv((long)kw * ck * COTP, 64) * 64);
+          };
+          while (CK > 4 && lds_words(CK) * 4 > FWD_LDS_BUDGET) CK /= 2;
+          const size_t lds = (size_t)lds_words(CK) * 4;
+          if ((long)lds > FWD_LDS_BUDGET) continue;
           double cost = (double)ty * tx * P * (1.0 + 0.05 * IH * IW / P + 0.15 * (NB + PB) / (double)(NB * PB)) *
-                        (1.0 + 0.02 * lwi + 0.3 / (kw * (CK / 4)));
+                        (1.0 + 0.02 * lwi + 0.3 / (kw * (CK / 4))) * (quad ? 1.0 : 1.08);
           if (cost < bestcost) {
             bestcost = cost;
             best = FwdPlan{NB, PB, TH, TW, ty, tx, CK, (int)mpa_cdiv(Cin, CK), IH, IW, LW, CHP, COT, COTP,
-                           (int)mpa_cdiv(Cout, COT), OH, OW, lds, true};
+                           (int)mpa_cdiv(Cout, COT), OH, OW, quad, lds, true};
           }
         }
       }
@@ -133,6 +147,144 @@ __device__ __forceinline__ void stage_window(float* __restrict__ dst, const floa
   }
 }
 
+// LDS-DMA staging (global_load_lds_dword): every LDS word of the image is fetched straight from global memory
+// -- or from a zero word when it lies outside the tensor -- with no VGPR round trip, so a whole tile (~60 loads per
+// lane) is in flight at once instead of being paid for in dependent batches.  The address arithmetic is branch-free
+// and 32-bit: measured with s_memtime stamps, a branchy per-word decode made the *issue* of a tile's loads take as
+// long as its MFMA loop.
+__device__ __attribute__((aligned(16))) float mpa_zero_src[256];
+
+__device__ __forceinline__ void glds_word(const float* src, float* lds_dst_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_dst_wave_base, 4, 0, 0);
+}
+
+// image [nch][chp] whose first nrows*lw words per channel hold rows of pitch lw; padded to `total64` words.
+// Offsets are 32-bit (one image's plane set < 2^31 elements).
+__device__ __forceinline__ void glds_stage_x(float* __restrict__ dst, const float* __restrict__ src, int lane, int wave,
+                                             int nch, int nrows, int ncols, int lw, int chp, int total64, int c0, int y0,
+                                             int x0, int C, int H, int W) {
+  int ch, r;
+  fast_divmod(wave * 64 + lane, chp, 1.0f / (float)chp, ch, r);
+  const float inv_lw = 1.0f / (float)lw;
+  const int used = nrows * lw;
+  const int cmax = min(nch, C - c0);          // channels of this window that exist
+  const float* zsrc = &mpa_zero_src[lane];
+  const int HW = H * W;
+  for (int base = wave * 64; base < total64; base += 256) {
+    int iy, ix;
+    fast_divmod(r, lw, inv_lw, iy, ix);
+    const int gy = y0 + iy, gx = x0 + ix;
+    const int ok = (int)(ch < cmax) & (int)(r < used) & (int)(ix < ncols) & (int)((unsigned)gy < (unsigned)H) &
+                   (int)((unsigned)gx < (unsigned)W);
+    const int off = (c0 + ch) * HW + gy * W + gx;
+    const float* ptr = ok ? src + off : zsrc;
+    glds_word(ptr, dst + base);
+    r += 256;
+    const int wrap = r >= chp;
+    r -= wrap ? chp : 0;
+    ch += wrap;
+    if (r >= chp) {                              // tiny images only (chp < 256)
+      while (r >= chp) { r -= chp; ch += 1; }
+    }
+  }
+}
+
+// image [nco][dcp] with the first th*dp words of a row holding (py, px); padded to `total64`
+__device__ __forceinline__ void glds_stage_dy(float* __restrict__ dst, const float* __restrict__ src, int lane, int wave,
+                                              int nco, int th, int dp, int dcp, int total64, int c0, int y0, int x0, int C,
+                                              int OH, int OW, int xlim) {
+  int co, r;
+  fast_divmod(wave * 64 + lane, dcp, 1.0f / (float)dcp, co, r);
+  const float inv_dp = 1.0f / (float)dp;
+  const float* zsrc = &mpa_zero_src[lane];
+  const int npx = th * dp;
+  const int cmax = min(nco, C - c0);
+  const int plane = OH * OW;
+  for (int base = wave * 64; base < total64; base += 256) {
+    int py, px;
+    fast_divmod(r, dp, inv_dp, py, px);
+    const int oy = y0 + py, ox = x0 + px;
+    const int ok = (int)(co < cmax) & (int)(r < npx) & (int)(oy < OH) & (int)(ox < xlim);
+    const int off = (c0 + co) * plane + oy * OW + ox;
+    const float* ptr = ok ? src + off : zsrc;
+    glds_word(ptr, dst + base);
+    r += 256;
+    const int wrap = r >= dcp;
+    r -= wrap ? dcp : 0;
+    co += wrap;
+    if (r >= dcp) {
+      while (r >= dcp) { r -= dcp; co += 1; }
+    }
+  }
+}
+
+// 16-byte LDS-DMA variants (4x fewer wave-instructions; the LDS-DMA path costs ~60-110 cycles per instruction per CU
+// whatever its width -- measured).  Require: W % 4 == 0, window x origin x0a % 4 == 0 (so every float4 is entirely
+// inside or outside the tensor), lw % 4 == 0, chp % 4 == 0.
+__device__ __forceinline__ void glds_quad(const float* src, float* lds_dst_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void glds_stage_x16(float* __restrict__ dst, const float* __restrict__ src, int lane, int wave,
+                                               int nch, int nrows, int lw, int chp, int total64, int c0, int y0, int x0a,
+                                               int C, int H, int W) {
+  const int lw4 = lw >> 2, chp4 = chp >> 2, total4 = total64 >> 2;     // everything in float4 units
+  int ch, r;
+  fast_divmod(wave * 64 + lane, chp4, 1.0f / (float)chp4, ch, r);
+  const float inv = 1.0f / (float)lw4;
+  const int used4 = nrows * lw4;
+  const int cmax = min(nch, C - c0);
+  const float* zsrc = &mpa_zero_src[(lane & 15) * 4];
+  const int HW = H * W;
+  for (int base = wave * 64; base < total4; base += 256) {
+    int iy, q;
+    fast_divmod(r, lw4, inv, iy, q);
+    const int gy = y0 + iy, gx = x0a + 4 * q;
+    const int ok = (int)(ch < cmax) & (int)(r < used4) & (int)((unsigned)gy < (unsigned)H) & (int)((unsigned)gx < (unsigned)W);
+    const int off = (c0 + ch) * HW + gy * W + gx;
+    glds_quad(ok ? src + off : zsrc, dst + (long)base * 4);
+    r += 256;
+    while (r >= chp4) { r -= chp4; ch += 1; }
+  }
+}
+
+// dY image [nco][dcp]: first th*dp words per cout are rows (py) of dp words; dp % 4 == 0, dcp % 4 == 0, OW % 4 == 0,
+// x0 % 4 == 0, xlim % 4 == 0
+__device__ __forceinline__ void glds_stage_dy16(float* __restrict__ dst, const float* __restrict__ src, int lane, int wave,
+                                                int nco, int th, int dp, int dcp, int total64, int c0, int y0, int x0, int C,
+                                                int OH, int OW, int xlim) {
+  const int dp4 = dp >> 2, dcp4 = dcp >> 2, total4 = total64 >> 2;
+  int co, r;
+  fast_divmod(wave * 64 + lane, dcp4, 1.0f / (float)dcp4, co, r);
+  const float inv = 1.0f / (float)dp4;
+  const float* zsrc = &mpa_zero_src[(lane & 15) * 4];
+  const int n4 = th * dp4;
+  const int cmax = min(nco, C - c0);
+  const int plane = OH * OW;
+  for (int base = wave * 64; base < total4; base += 256) {
+    int py, q;
+    fast_divmod(r, dp4, inv, py, q);
+    const int oy = y0 + py, ox = x0 + 4 * q;
+    const int ok = (int)(co < cmax) & (int)(r < n4) & (int)(oy < OH) & (int)(ox < xlim);
+    const int off = (c0 + co) * plane + oy * OW + ox;
+    glds_quad(ok ? src + off : zsrc, dst + (long)base * 4);
+    r += 256;
+    while (r >= dcp4) { r -= dcp4; co += 1; }
+  }
+}
+
+// linear copy of n4 float4 (16-byte LDS-DMA): dst/src 16-byte aligned
+__device__ __forceinline__ void glds_copy16(float* __restrict__ dst, const float* __restrict__ src, int tid, int n4) {
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int base = wave * 64; base < n4; base += 256) {
+    if (base + lane < n4)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long)(base + lane) * 4),
+                                       (__attribute__((address_space(3))) void*)(dst + (long)base * 4), 16, 0, 0);
+  }
+}
+
 struct ConvFwdParams {
   const float* x;
   const float* wp;
@@ -140,6 +292,9 @@ struct ConvFwdParams {
   float* y;
   int B, Cin, H, W, Cout, OH, OW, kh, kw, sh, sw, ph, pw;
   int TH, TW, tilesY, tilesX, CK, nChunks, IH, IW, LW, CHP, COT, COTP;
+  int IN64, SL64;      // LDS words of the input tile / one filter slab, rounded up to multiples of 64
+  int quad;            // 16-byte LDS-DMA staging of the input tile (window origin rounded down to a multiple of 4)
+  int dbg;             // diagnostics (env MPA_DEBUG_FWD): 1 = stage only once, 2 = skip the MFMA loops
   int act;
   float slope;
   long outBS, outCS;   // output batch / channel strides (floats)
@@ -151,7 +306,7 @@ template <int NB, int PB>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lds_in = lds;
-  float* lds_w = lds + p.CK * p.CHP;
+  float* lds_w0 = lds + p.IN64;          // two filter-slab buffers: slab dy+1 streams in while dy is consumed
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int bid = blockIdx.x;
   const int tx = bid % p.tilesX;
@@ -164,13 +319,15 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
   const int npix = p.TH * p.TW;
   const int kq = lane >> 4, l16 = lane & 15;
 
+  const int x0a = p.quad ? (ix0 & ~3) : ix0;     // 4-aligned window origin for the 16-byte staging path
+  const int xshift = ix0 - x0a;
   int boff[PB];
 #pragma unroll
   for (int pb = 0; pb < PB; ++pb) {
     int pix = (wave * PB + pb) * 16 + l16;
     int pc = pix < npix ? pix : npix - 1;
     int py = pc / p.TW, px = pc - py * p.TW;
-    boff[pb] = kq * p.CHP + py * p.sh * p.LW + px * p.sw;
+    boff[pb] = kq * p.CHP + py * p.sh * p.LW + px * p.sw + xshift;
   }
   const int aoff = kq * p.COTP + l16;
   f32x4 acc[NB][PB];
@@ -185,16 +342,22 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
   const int astep = p.CK * p.COTP;
 
   for (int c = 0; c < p.nChunks; ++c) {
+    __syncthreads();   // every wave is done with the previous chunk's tile and slabs
+    const bool do_stage = p.dbg != 1 || c == 0;
+    if (do_stage) {
+      if (p.quad)
+        glds_stage_x16(lds_in, xb, lane, wave, p.CK, p.IH, p.LW, p.CHP, p.IN64, c * p.CK, iy0, x0a, p.Cin, p.H, p.W);
+      else
+        glds_stage_x(lds_in, xb, lane, wave, p.CK, p.IH, p.IW, p.LW, p.CHP, p.IN64, c * p.CK, iy0, ix0, p.Cin, p.H, p.W);
+      glds_copy16(lds_w0, wtile + (long)(c * p.kh) * slab, tid, slab / 4);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    stage_window(lds_in, xb, tid, p.CK, p.IH, p.IW, p.CHP, p.LW, c * p.CK, iy0, ix0, p.Cin, p.H, p.W, p.W);
     for (int dy = 0; dy < p.kh; ++dy) {
-      if (dy > 0) __syncthreads();
-      {
-        const float4* ws = reinterpret_cast<const float4*>(wtile + (long)(c * p.kh + dy) * slab);
-        float4* wd = reinterpret_cast<float4*>(lds_w);
-        for (int i = tid; i < slab / 4; i += 256) wd[i] = ws[i];
-      }
-      __syncthreads();
+      const float* lds_w = lds_w0 + (dy & 1) * p.SL64;
+      if (dy + 1 < p.kh && do_stage)
+        glds_copy16(lds_w0 + ((dy + 1) & 1) * p.SL64, wtile + (long)(c * p.kh + dy + 1) * slab, tid, slab / 4);
+      if (p.dbg != 2)
       for (int j = 0; j < p.CK / 4; ++j) {
         const float* ap = lds_w + j * 4 * p.COTP + aoff;
         const float* bp = lds_in + j * 4 * p.CHP + dy * p.LW;
@@ -231,6 +394,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
               acc[nb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nb], bv[pb], acc[nb][pb], 0, 0, 0);
         }
       }
+      if (dy + 1 < p.kh) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next slab has landed
+        __syncthreads();                                   // ... and everyone is done reading this one
+      }
     }
   }
 
@@ -258,9 +425,21 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
   }
 }
 
+template <int NB, int PB>
+void fwd_allow_big_lds() {
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<NB, PB>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    done = true;
+  }
+}
+
 template <int NB>
 int launch_fwd_nb(const FwdPlan& pl, const ConvFwdParams& p, hipStream_t s) {
   dim3 grid((unsigned)(p.B * pl.tilesY * pl.tilesX), (unsigned)pl.coTiles);
+  fwd_allow_big_lds<NB, 1>(); fwd_allow_big_lds<NB, 2>(); fwd_allow_big_lds<NB, 4>(); fwd_allow_big_lds<NB, 6>();
+  if constexpr (NB <= 4) fwd_allow_big_lds<NB, 8>();
+  if constexpr (NB <= 2) fwd_allow_big_lds<NB, 12>();
   switch (pl.PB) {
     case 1: MPA_LAUNCH((conv_fwd_kernel<NB, 1>), grid, dim3(256), pl.lds_bytes, s, p); break;
     case 2: MPA_LAUNCH((conv_fwd_kernel<NB, 2>), grid, dim3(256), pl.lds_bytes, s, p); break;
@@ -416,56 +595,6 @@ WgPlan plan_wgrad(const mpa_conv_desc* d) {
   return best;
 }
 
-// LDS-DMA staging (global_load_lds_dword): every LDS word of the image is fetched straight from global memory
-// -- or from a zero word when it lies outside the tensor -- with no VGPR round trip, so a whole tile (~60 loads per
-// lane) is in flight at once instead of being paid for in dependent batches.
-__device__ float mpa_zero_src[64];
-
-__device__ __forceinline__ void glds_word(const float* src, float* lds_dst_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                   (__attribute__((address_space(3))) void*)lds_dst_wave_base, 4, 0, 0);
-}
-
-// image [nch][nrows][lw] (channel pitch nrows*lw exactly), padded to a multiple of 64 words (`total64`)
-__device__ __forceinline__ void glds_stage_x(float* __restrict__ dst, const float* __restrict__ src, int lane, int wave,
-                                             int nch, int nrows, int ncols, int lw, int total64, int c0, int y0, int x0,
-                                             int C, int H, int W) {
-  int ch, iy, ix, row, dq, dr;
-  fast_divmod(wave * 64 + lane, lw, 1.0f / (float)lw, row, ix);
-  fast_divmod(row, nrows, 1.0f / (float)nrows, ch, iy);
-  fast_divmod(256, lw, 1.0f / (float)lw, dq, dr);
-  const float* zsrc = &mpa_zero_src[lane];
-  for (int base = wave * 64; base < total64; base += 256) {
-    const int gc = c0 + ch, gy = y0 + iy, gx = x0 + ix;
-    const bool ok = ch < nch && ix < ncols && gc < C && gy >= 0 && gy < H && gx >= 0 && gx < W;
-    glds_word(ok ? src + ((long)gc * H + gy) * W + gx : zsrc, dst + base);
-    ix += dr;
-    iy += dq;
-    if (ix >= lw) { ix -= lw; iy += 1; }
-    while (iy >= nrows) { iy -= nrows; ch += 1; }
-  }
-}
-
-// image [nco][dcp] with the first th*dp words of a row holding (py, px); padded to `total64`
-__device__ __forceinline__ void glds_stage_dy(float* __restrict__ dst, const float* __restrict__ src, int lane, int wave,
-                                              int nco, int th, int dp, int dcp, int total64, int c0, int y0, int x0, int C,
-                                              int OH, int OW, int xlim) {
-  int co, r;
-  fast_divmod(wave * 64 + lane, dcp, 1.0f / (float)dcp, co, r);
-  const float inv_dp = 1.0f / (float)dp;
-  const float* zsrc = &mpa_zero_src[lane];
-  const int npx = th * dp;
-  for (int base = wave * 64; base < total64; base += 256) {
-    int py, px;
-    fast_divmod(r, dp, inv_dp, py, px);
-    const int gc = c0 + co, oy = y0 + py, ox = x0 + px;
-    const bool ok = co < nco && r < npx && gc < C && oy < OH && ox < xlim;
-    glds_word(ok ? src + ((long)gc * OH + oy) * OW + ox : zsrc, dst + base);
-    r += 256;
-    while (r >= dcp) { r -= dcp; co += 1; }
-  }
-}
-
 struct WgParams {
   const float* x;
   const float* dy;
@@ -516,8 +645,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgParams p) {
     const int oy0 = ty * p.TH, ox0 = tx * p.TW;
     const int iy0 = oy0 * p.sh - p.ph, ix0 = ox0 * p.sw - p.pw;
     __syncthreads();
-    glds_stage_x(lds_x, p.x + (long)b * p.Cin * p.H * p.W, lane, wave, p.XCH, p.IH, p.IW, p.LW, p.TX64, ci_first, iy0, ix0,
-                 p.Cin, p.H, p.W);
+    glds_stage_x(lds_x, p.x + (long)b * p.Cin * p.H * p.W, lane, wave, p.XCH, p.IH, p.IW, p.LW, p.XCHP, p.TX64, ci_first,
+                 iy0, ix0, p.Cin, p.H, p.W);
     // dY tile: columns >= TW belong to the neighbouring tile -> clip the readable width at ox0+TW
     glds_stage_dy(lds_dy, p.dy + (long)b * p.Cout * p.OH * p.OW, lane, wave, p.COT, p.TH, p.DP, p.DCP, p.TD64, cot * p.COT,
                   oy0, ox0, p.Cout, p.OH, p.OW, min(p.OW, ox0 + p.TW));
@@ -589,6 +718,8 @@ struct Wg15Params {
   float* ws;
   int B, Cin, H, W, Cout, OH, OW;
   int COT, TH, TW, DP, tilesY, tilesX, IH, IW, DCP, S, Ntot, TX64, TD64;
+  int quad;  // 16-byte LDS-DMA staging (aligned geometry): the X window then starts one column further left (ox0-8)
+  int dbg;   // diagnostics (env MPA_DEBUG_WG15): 1 = stage only the first tile, 2 = skip the MFMA loop
 };
 
 template <int NBC, int CIW>
@@ -614,7 +745,7 @@ __global__ __launch_bounds__(256) void conv_wgrad15_kernel(const Wg15Params p) {
 
   const int tilesPerImg = p.tilesY * p.tilesX;
   const long totalTiles = (long)p.B * tilesPerImg;
-  const float* bbase = lds_x + wave * CIW * xchp + kq + l16;
+  const float* bbase = lds_x + wave * CIW * xchp + kq + l16 + (p.quad ? 1 : 0);
   const float* abase = lds_dy + l16 * p.DCP + kq;
   for (long tile = split; tile < totalTiles; tile += p.S) {
     const int b = (int)(tile / tilesPerImg);
@@ -622,12 +753,22 @@ __global__ __launch_bounds__(256) void conv_wgrad15_kernel(const Wg15Params p) {
     const int ty = tr / p.tilesX, tx = tr - ty * p.tilesX;
     const int oy0 = ty * p.TH, ox0 = tx * p.TW;
     __syncthreads();
-    glds_stage_x(lds_x, p.x + (long)b * p.Cin * p.H * p.W, lane, wave, 4 * CIW, p.IH, p.IW, W15_PITCH, p.TX64, ci_first,
-                 oy0 - 7, ox0 - 7, p.Cin, p.H, p.W);
-    glds_stage_dy(lds_dy, p.dy + (long)b * p.Cout * p.OH * p.OW, lane, wave, p.COT, p.TH, p.DP, p.DCP, p.TD64, cot * p.COT,
-                  oy0, ox0, p.Cout, p.OH, p.OW, min(p.OW, ox0 + p.TW));
+    if (p.dbg != 1 || tile == split) {
+      if (p.quad) {
+        glds_stage_x16(lds_x, p.x + (long)b * p.Cin * p.H * p.W, lane, wave, 4 * CIW, p.IH, W15_PITCH, xchp, p.TX64,
+                       ci_first, oy0 - 7, ox0 - 8, p.Cin, p.H, p.W);
+        glds_stage_dy16(lds_dy, p.dy + (long)b * p.Cout * p.OH * p.OW, lane, wave, p.COT, p.TH, p.DP, p.DCP, p.TD64,
+                        cot * p.COT, oy0, ox0, p.Cout, p.OH, p.OW, min(p.OW, ox0 + p.TW));
+      } else {
+        glds_stage_x(lds_x, p.x + (long)b * p.Cin * p.H * p.W, lane, wave, 4 * CIW, p.IH, p.IW, W15_PITCH, xchp, p.TX64,
+                     ci_first, oy0 - 7, ox0 - 7, p.Cin, p.H, p.W);
+        glds_stage_dy(lds_dy, p.dy + (long)b * p.Cout * p.OH * p.OW, lane, wave, p.COT, p.TH, p.DP, p.DCP, p.TD64,
+                      cot * p.COT, oy0, ox0, p.Cout, p.OH, p.OW, min(p.OW, ox0 + p.TW));
+      }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (p.dbg == 2) continue;
     if (do_bias) {
       const int co = tid >> 1, part = tid & 1;
       if (co < p.COT) {
@@ -701,7 +842,7 @@ __global__ __launch_bounds__(256) void conv_wgrad15_kernel(const Wg15Params p) {
 }
 
 struct Wg15Plan {
-  int NBC, CIW, COT, coTiles, ciGroups, TH, TW, DP, tilesY, tilesX, IH, IW, DCP, S, TX64, TD64;
+  int NBC, CIW, COT, coTiles, ciGroups, TH, TW, DP, tilesY, tilesX, IH, IW, DCP, S, TX64, TD64, quad;
   size_t lds_bytes;
   bool ok;
 };
@@ -721,11 +862,13 @@ Wg15Plan plan_wgrad15(const mpa_conv_desc* d) {
   for (int txn = 1; txn <= OW; ++txn) {
     const int TW = (int)mpa_cdiv(OW, txn);
     const int DP = (int)mpa_cdiv(TW, 4) * 4;
-    const int IW = DP + 14;
+    // 16-byte LDS-DMA needs every tile origin and the tensor width 4-aligned; the X window then spans DP+15 columns
+    const int quad = (OW % 4 == 0 && TW % 4 == 0) ? 1 : 0;
+    const int IW = DP + 14 + quad;
     if (IW > W15_PITCH) continue;
     for (int TH = std::min(OH, 32); TH >= 1; --TH) {
       const int IH = TH + 14;
-      const int DCP = round_mod(TH * DP, 32, 2);
+      const int DCP = quad ? round_mod(TH * DP, 32, 4) : round_mod(TH * DP, 32, 2);
       const long tx64 = mpa_cdiv((long)4 * pl.CIW * IH * W15_PITCH, 64) * 64, td64 = mpa_cdiv((long)pl.COT * DCP, 64) * 64;
       if ((tx64 + td64) * 4 > budget) continue;
       const int ty = (int)mpa_cdiv(OH, TH);
@@ -735,6 +878,7 @@ Wg15Plan plan_wgrad15(const mpa_conv_desc* d) {
       if (cost < bestcost) {
         bestcost = cost;
         pl.TH = TH; pl.TW = TW; pl.DP = DP; pl.tilesY = ty; pl.tilesX = txn; pl.IH = IH; pl.IW = IW; pl.DCP = DCP;
+        pl.quad = quad;
         pl.TX64 = (int)tx64; pl.TD64 = (int)td64; pl.lds_bytes = (size_t)(tx64 + td64) * 4; pl.ok = true;
       }
       break;
@@ -820,6 +964,10 @@ static int conv_fwd_impl(int B, int Cin, int H, int W, int Cout, int kh, int kw,
   p.kh = kh; p.kw = kw; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw;
   p.TH = pl.TH; p.TW = pl.TW; p.tilesY = pl.tilesY; p.tilesX = pl.tilesX; p.CK = pl.CK; p.nChunks = pl.nChunks;
   p.IH = pl.IH; p.IW = pl.IW; p.LW = pl.LW; p.CHP = pl.CHP; p.COT = pl.COT; p.COTP = pl.COTP;
+  p.IN64 = (int)(mpa_cdiv((long)pl.CK * pl.CHP, 64) * 64);
+  p.SL64 = (int)(mpa_cdiv((long)kw * pl.CK * pl.COTP, 64) * 64);
+  p.quad = pl.quad;
+  { const char* e = getenv("MPA_DEBUG_FWD"); p.dbg = e ? atoi(e) : 0; }
   p.act = act; p.slope = slope;
   p.outBS = outBS; p.outCS = outCS; p.outRS = outRS; p.outXmul = outXmul; p.outCdiv = outCdiv;
   return launch_fwd(pl, p, s);
@@ -872,8 +1020,8 @@ int mpa_conv2d_describe_plan(const mpa_conv_desc* d, int mode, char* buf, int bu
     f = plan_fwd(g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw);
   }
   if (!f.ok) return MPA_ERR_UNSUPPORTED;
-  snprintf(buf, buflen, "fwd<%d,%d> COT=%d coTiles=%d CK=%d chunks=%d tile=%dx%d tiles=%dx%d halo=%dx%d LW=%d lds=%zuB", f.NB,
-           f.PB, f.COT, f.coTiles, f.CK, f.nChunks, f.TH, f.TW, f.tilesY, f.tilesX, f.IH, f.IW, f.LW, f.lds_bytes);
+  snprintf(buf, buflen, "fwd<%d,%d> COT=%d coTiles=%d CK=%d chunks=%d tile=%dx%d tiles=%dx%d halo=%dx%d LW=%d quad=%d lds=%zuB",
+           f.NB, f.PB, f.COT, f.coTiles, f.CK, f.nChunks, f.TH, f.TW, f.tilesY, f.tilesX, f.IH, f.IW, f.LW, f.quad, f.lds_bytes);
   return MPA_OK;
 }
 
@@ -898,7 +1046,8 @@ int mpa_conv2d_bwd_weight(const mpa_conv_desc* d, const float* x, const float* d
     q.x = x; q.dy = dy; q.ws = (float*)workspace;
     q.B = d->B; q.Cin = d->Cin; q.H = d->H; q.W = d->W; q.Cout = d->Cout; q.OH = d->H; q.OW = d->W;
     q.COT = p15.COT; q.TH = p15.TH; q.TW = p15.TW; q.DP = p15.DP; q.tilesY = p15.tilesY; q.tilesX = p15.tilesX;
-    q.IH = p15.IH; q.IW = p15.IW; q.DCP = p15.DCP; q.S = p15.S; q.Ntot = Ntot; q.TX64 = p15.TX64; q.TD64 = p15.TD64;
+    q.IH = p15.IH; q.IW = p15.IW; q.DCP = p15.DCP; q.S = p15.S; q.Ntot = Ntot; q.TX64 = p15.TX64; q.TD64 = p15.TD64; q.quad = p15.quad;
+    { const char* e = getenv("MPA_DEBUG_WG15"); q.dbg = e ? atoi(e) : 0; }
     hipStream_t s15 = (hipStream_t)stream;
     dim3 grid15((unsigned)p15.S, (unsigned)p15.ciGroups, (unsigned)p15.coTiles);
     static bool attr_set = false;
