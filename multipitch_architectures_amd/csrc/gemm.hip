@@ -18,37 +18,78 @@ struct GemmParams {
   float* C;
   long lda_m, lda_k, ldb_k, ldb_n, ldc;
   int M, N, K, accumulate, act;
+  int kchunk;   // split-K: blockIdx.z owns k in [z*kchunk, (z+1)*kchunk); partial results are atomically added into C
 };
 
-// stage an (R x BK) operand tile: elem(r,k) = src[r*ld_r + k*ld_k]; k contiguous -> r-major image (pitch BK+2),
-// else k-major image (pitch R+16)
+// Operand tile staging, split in two halves so that the global loads of k-tile t+1 are in flight while the MFMAs of
+// k-tile t run (register prefetch): tile_load() fills registers, tile_store() writes them to the LDS image.
+//   k contiguous (ld_k == 1): float4 along k, r-major image (pitch BK+4: 16-byte aligned rows, bank-skewed)
+//   r contiguous (ld_r == 1): float4 along r, k-major image (pitch R+16)
+//   otherwise              : scalar loads, k-major image
 template <int R>
-__device__ __forceinline__ void stage_operand(float* __restrict__ img, const float* __restrict__ src, long ld_r, long ld_k,
-                                              int r0, int k0, int Rlim, int K, int tid) {
-  float v[(R * BK) / 256];
+struct TileRegs {
+  float4 v[(R * BK) / 1024];
+};
+
+template <int R>
+__device__ __forceinline__ void tile_load(TileRegs<R>& t, const float* __restrict__ src, long ld_r, long ld_k, int r0, int k0,
+                                          int Rlim, int K, int tid, bool vec_ok) {
+  constexpr int N4 = (R * BK) / 1024;
   if (ld_k == 1) {
 #pragma unroll
-    for (int it = 0; it < (R * BK) / 256; ++it) {
-      const int e = it * 256 + tid;
-      const int r = e / BK, k = e % BK;
-      v[it] = (r0 + r < Rlim && k0 + k < K) ? src[(long)(r0 + r) * ld_r + (k0 + k)] : 0.f;
-    }
-#pragma unroll
-    for (int it = 0; it < (R * BK) / 256; ++it) {
-      const int e = it * 256 + tid;
-      img[(e / BK) * (BK + 2) + (e % BK)] = v[it];
+    for (int it = 0; it < N4; ++it) {
+      const int e = it * 256 + tid;            // float4 index: BK/4 per row
+      const int r = e / (BK / 4), k = (e % (BK / 4)) * 4;
+      const float* ptr = src + (long)(r0 + r) * ld_r + (k0 + k);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r0 + r < Rlim) {
+        if (vec_ok && k0 + k + 3 < K) v = *reinterpret_cast<const float4*>(ptr);
+        else {
+          if (k0 + k < K) v.x = ptr[0];
+          if (k0 + k + 1 < K) v.y = ptr[1];
+          if (k0 + k + 2 < K) v.z = ptr[2];
+          if (k0 + k + 3 < K) v.w = ptr[3];
+        }
+      }
+      t.v[it] = v;
     }
   } else {
 #pragma unroll
-    for (int it = 0; it < (R * BK) / 256; ++it) {
-      const int e = it * 256 + tid;
-      const int k = e / R, r = e % R;
-      v[it] = (r0 + r < Rlim && k0 + k < K) ? src[(long)(r0 + r) * ld_r + (long)(k0 + k) * ld_k] : 0.f;
+    for (int it = 0; it < N4; ++it) {
+      const int e = it * 256 + tid;            // float4 index: R/4 per k row
+      const int k = e / (R / 4), r = (e % (R / 4)) * 4;
+      const float* ptr = src + (long)(r0 + r) * ld_r + (long)(k0 + k) * ld_k;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k0 + k < K) {
+        if (vec_ok && ld_r == 1 && r0 + r + 3 < Rlim) v = *reinterpret_cast<const float4*>(ptr);
+        else {
+          if (r0 + r < Rlim) v.x = ptr[0];
+          if (r0 + r + 1 < Rlim) v.y = ptr[ld_r];
+          if (r0 + r + 2 < Rlim) v.z = ptr[2 * ld_r];
+          if (r0 + r + 3 < Rlim) v.w = ptr[3 * ld_r];
+        }
+      }
+      t.v[it] = v;
     }
+  }
+}
+
+template <int R>
+__device__ __forceinline__ void tile_store(const TileRegs<R>& t, float* __restrict__ img, long ld_k, int tid) {
+  constexpr int N4 = (R * BK) / 1024;
+  if (ld_k == 1) {
 #pragma unroll
-    for (int it = 0; it < (R * BK) / 256; ++it) {
+    for (int it = 0; it < N4; ++it) {
       const int e = it * 256 + tid;
-      img[(e / R) * (R + 16) + (e % R)] = v[it];
+      const int r = e / (BK / 4), k = (e % (BK / 4)) * 4;
+      *reinterpret_cast<float4*>(img + r * (BK + 4) + k) = t.v[it];
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < N4; ++it) {
+      const int e = it * 256 + tid;
+      const int k = e / (R / 4), r = (e % (R / 4)) * 4;
+      *reinterpret_cast<float4*>(img + k * (R + 16) + r) = t.v[it];
     }
   }
 }
@@ -57,27 +98,43 @@ __device__ __forceinline__ void stage_operand(float* __restrict__ img, const flo
 template <int WM, int WN>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   constexpr int BMt = 2 * WM * 16, BNt = 2 * WN * 16;
-  constexpr int AF = (BMt * (BK + 2) > BK * (BMt + 16)) ? BMt * (BK + 2) : BK * (BMt + 16);
-  constexpr int BF = (BNt * (BK + 2) > BK * (BNt + 16)) ? BNt * (BK + 2) : BK * (BNt + 16);
+  constexpr int AF = (BMt * (BK + 4) > BK * (BMt + 16)) ? BMt * (BK + 4) : BK * (BMt + 16);
+  constexpr int BF = (BNt * (BK + 4) > BK * (BNt + 16)) ? BNt * (BK + 4) : BK * (BNt + 16);
   __shared__ __attribute__((aligned(16))) float As[AF];
   __shared__ __attribute__((aligned(16))) float Bs[BF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.y * BMt, n0 = blockIdx.x * BNt;
   const int wm = (wave >> 1) * WM * 16, wn = (wave & 1) * WN * 16;
   const int kq = lane >> 4, l16 = lane & 15;
-  const int a_sr = p.lda_k == 1 ? (BK + 2) : 1, a_sk = p.lda_k == 1 ? 1 : (BMt + 16);
-  const int b_sr = p.ldb_k == 1 ? (BK + 2) : 1, b_sk = p.ldb_k == 1 ? 1 : (BNt + 16);
+  const int a_sr = p.lda_k == 1 ? (BK + 4) : 1, a_sk = p.lda_k == 1 ? 1 : (BMt + 16);
+  const int b_sr = p.ldb_k == 1 ? (BK + 4) : 1, b_sk = p.ldb_k == 1 ? 1 : (BNt + 16);
+  // float4 global loads need 16-byte aligned rows
+  const bool a_vec = ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0) &&
+                     (p.lda_k == 1 ? (p.lda_m % 4 == 0) : (p.lda_m == 1 && p.lda_k % 4 == 0));
+  const bool b_vec = ((reinterpret_cast<uintptr_t>(p.B) & 15) == 0) &&
+                     (p.ldb_k == 1 ? (p.ldb_n % 4 == 0) : (p.ldb_n == 1 && p.ldb_k % 4 == 0));
   f32x4 acc[WM][WN];
 #pragma unroll
   for (int i = 0; i < WM; ++i)
 #pragma unroll
     for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int k0 = 0; k0 < p.K; k0 += BK) {
+  TileRegs<BMt> ra;
+  TileRegs<BNt> rb;
+  const bool splitk = gridDim.z > 1;
+  const int kbeg = blockIdx.z * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+  tile_load<BMt>(ra, p.A, p.lda_m, p.lda_k, m0, kbeg, p.M, kend, tid, a_vec);
+  tile_load<BNt>(rb, p.B, p.ldb_n, p.ldb_k, n0, kbeg, p.N, kend, tid, b_vec);
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    __syncthreads();                       // previous tile fully consumed
+    tile_store<BMt>(ra, As, p.lda_k, tid);
+    tile_store<BNt>(rb, Bs, p.ldb_k, tid);
     __syncthreads();
-    stage_operand<BMt>(As, p.A, p.lda_m, p.lda_k, m0, k0, p.M, p.K, tid);
-    stage_operand<BNt>(Bs, p.B, p.ldb_n, p.ldb_k, n0, k0, p.N, p.K, tid);
-    __syncthreads();
+    if (k0 + BK < kend) {                  // prefetch the next k-tile while this one is multiplied
+      tile_load<BMt>(ra, p.A, p.lda_m, p.lda_k, m0, k0 + BK, p.M, kend, tid, a_vec);
+      tile_load<BNt>(rb, p.B, p.ldb_n, p.ldb_k, n0, k0 + BK, p.N, kend, tid, b_vec);
+    }
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 4) {
       float a[WM], b[WN];
@@ -98,13 +155,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     for (int j = 0; j < WN; ++j) {
       const int n = n0 + wn + j * 16 + l16;
       if (n >= p.N) continue;
-      const float bv = p.bias ? p.bias[n] : 0.f;
+      const float bv = (p.bias && blockIdx.z == 0) ? p.bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm + i * 16 + kq * 4 + r;
         if (m >= p.M) continue;
         float v = acc[i][j][r] + bv;
         float* c = p.C + (long)m * p.ldc + n;
+        if (splitk) { atomicAdd(c, v); continue; }      // C was zeroed (or holds the value to accumulate onto)
         if (p.accumulate) v += *c;
         *c = mpa_apply_act(v, p.act, 0.f);
       }
@@ -112,8 +170,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 }
 
 template <int WM, int WN>
-void launch_gemm(const GemmParams& p, hipStream_t s) {
-  dim3 grid((unsigned)mpa_cdiv(p.N, 2 * WN * 16), (unsigned)mpa_cdiv(p.M, 2 * WM * 16));
+void launch_gemm(const GemmParams& p, int splits, hipStream_t s) {
+  dim3 grid((unsigned)mpa_cdiv(p.N, 2 * WN * 16), (unsigned)mpa_cdiv(p.M, 2 * WM * 16), (unsigned)splits);
   MPA_LAUNCH((gemm_kernel<WM, WN>), grid, dim3(256), 0, s, p);
 }
 
@@ -123,16 +181,44 @@ extern "C" int mpa_gemm(const float* A, int64_t lda_m, int64_t lda_k, const floa
                         const float* bias, float* C, int64_t ldc, int M, int N, int K, int accumulate, int act,
                         void* stream) {
   if (!A || !Bm || !C || M <= 0 || N <= 0 || K <= 0) return MPA_ERR_ARG;
-  GemmParams p{A, Bm, bias, C, (long)lda_m, (long)lda_k, (long)ldb_k, (long)ldb_n, (long)ldc, M, N, K, accumulate, act};
+  GemmParams p{A, Bm, bias, C, (long)lda_m, (long)lda_k, (long)ldb_k, (long)ldb_n, (long)ldc, M, N, K, accumulate, act, K};
   hipStream_t s = (hipStream_t)stream;
-  // largest tile that still gives every CU (256) a couple of workgroups
+  // largest tile that still gives every CU (256) a couple of workgroups ...
   const long b128 = mpa_cdiv(M, 128) * mpa_cdiv(N, 128);
   const long b12864 = mpa_cdiv(M, 128) * mpa_cdiv(N, 64);
   const long b64128 = mpa_cdiv(M, 64) * mpa_cdiv(N, 128);
-  if (b128 >= 512) launch_gemm<4, 4>(p, s);
-  else if (b12864 >= 384 && M >= N) launch_gemm<4, 2>(p, s);
-  else if (b64128 >= 384) launch_gemm<2, 4>(p, s);
-  else if (b12864 >= 384) launch_gemm<4, 2>(p, s);
-  else launch_gemm<2, 2>(p, s);
+  const long b64 = mpa_cdiv(M, 64) * mpa_cdiv(N, 64);
+  int variant;            // 0: 128x128, 1: 128x64, 2: 64x128, 3: 64x64
+  long blocks;
+  if (b128 >= 384) { variant = 0; blocks = b128; }
+  else if (b12864 >= 384 && M >= N) { variant = 1; blocks = b12864; }
+  else if (b64128 >= 384) { variant = 2; blocks = b64128; }
+  else if (b12864 >= 384) { variant = 1; blocks = b12864; }
+  else if (b64 >= 256) { variant = 3; blocks = b64; }
+  else {
+    // ... or, for small outputs with a long reduction (weight gradients: K = batch*positions), the largest tile and a
+    // split of K over blockIdx.z with atomic accumulation (order of the fp32 adds is not fixed; no activation)
+    variant = (M >= 128 && N >= 128) ? 0 : 3;
+    blocks = variant == 0 ? b128 : b64;
+  }
+  int splits = 1;
+  if (blocks < 256 && act == MPA_ACT_NONE && K >= 1024) {
+    splits = (int)std::min<long>(mpa_cdiv(768, blocks), K / 256);
+    if (splits < 1) splits = 1;
+  }
+  if (splits > 1) {
+    p.kchunk = (int)(mpa_cdiv(mpa_cdiv(K, splits), BK) * BK);
+    splits = (int)mpa_cdiv(K, p.kchunk);
+    if (!accumulate) {
+      if (ldc == N) { if (hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, s) != hipSuccess) return MPA_ERR_LAUNCH; }
+      else if (hipMemset2DAsync(C, sizeof(float) * ldc, 0, sizeof(float) * N, M, s) != hipSuccess) return MPA_ERR_LAUNCH;
+    }
+  }
+  switch (variant) {
+    case 0: launch_gemm<4, 4>(p, splits, s); break;
+    case 1: launch_gemm<4, 2>(p, splits, s); break;
+    case 2: launch_gemm<2, 4>(p, splits, s); break;
+    default: launch_gemm<2, 2>(p, splits, s); break;
+  }
   return mpa_launch_status();
 }
