@@ -77,11 +77,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; MPA_DIST_BACKEND=gloo + fewer devices than ranks is only for rehearsing the N>1 code path
+    # on a single-GPU box (ranks then share a device and the collectives go through the host)
+    backend = os.environ.get("MPA_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and local_rank >= ndev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK={local_rank} but only {ndev} GPUs are visible")
+    torch.cuda.set_device(local_rank % ndev)
+    dev = torch.device("cuda", local_rank % ndev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     cfg = CONFIGS[args.config]
     torch.manual_seed(0)                                    # PyTorch default init, seed 0 (timing is value independent)
@@ -143,6 +152,12 @@ def main():
         H, W = args.frames, 216
         kflops = 2.0 * B_loc * dom.out_channels * dom.in_channels * dom.kernel_size[0] * dom.kernel_size[1] * H * W
         kms = sum(probe_ms) / max(len(probe_ms), 1)
+        # HBM bytes per launch of that kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/);
+        # only valid for the configuration it was collected on
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tfile) and args.config == "SAUnet:L" and B_loc == 256 and args.frames == 75:
+            traffic = json.load(open(tfile))["traffic_bytes"]
         achieved = kflops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
         out = {
             "metric": "HCQT frames/sec (train step), SAUnet:L" if args.config == "SAUnet:L" else f"HCQT frames/sec (train step), {args.config}",
@@ -154,7 +169,7 @@ def main():
                                    f"BASELINE.json configs[3]", "global_batch": args.global_batch,
                        "frames": args.frames, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                          "kernel": f"conv_fwd_kernel {dom.in_channels}->{dom.out_channels} 15x15 @{H}x{W} "
                                    f"(upconv4.double_conv.4), local batch {B_loc}", "launch_ms": kms,
                          "launches_timed": len(probe_ms), "algorithmic_gflop_per_launch": kflops / 1e9},

@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
 
   for (int c = 0; c < p.nChunks; ++c) {
     __syncthreads();   // every wave is done with the previous chunk's tile and slabs
-    const bool do_stage = p.dbg != 1 || c == 0;
+    const bool do_stage = (p.dbg != 1 && p.dbg != 3) || c == 0;
     if (do_stage) {
       if (p.quad)
         glds_stage_x16(lds_in, xb, lane, wave, p.CK, p.IH, p.LW, p.CHP, p.IN64, c * p.CK, iy0, x0a, p.Cin, p.H, p.W);
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
               acc[nb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nb], bv[pb], acc[nb][pb], 0, 0, 0);
         }
       }
-      if (dy + 1 < p.kh) {
+      if (dy + 1 < p.kh && p.dbg != 3) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next slab has landed
         __syncthreads();                                   // ... and everyone is done reading this one
       }
