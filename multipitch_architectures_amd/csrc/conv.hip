@@ -37,66 +37,80 @@ inline int round_mod(int v, int m, int r) {  // smallest x >= v with x % m == r
   return x;
 }
 
-FwdPlan plan_fwd(int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw) {
+FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw) {
   FwdPlan best{};
   best.ok = false;
   const int OH = (H + 2 * ph - kh) / sh + 1, OW = (W + 2 * pw - kw) / sw + 1;
   if (OH <= 0 || OW <= 0) return best;
-  // cout blocking
-  const int nbs[4] = {1, 2, 4, 5};
-  int NB = 1;
-  long bestpad = -1;
-  for (int i = 0; i < 4; ++i) {
-    int cot = nbs[i] * 16;
-    long pad = (long)mpa_cdiv(Cout, cot) * cot;
-    if (bestpad < 0 || pad < bestpad || (pad == bestpad && nbs[i] > NB)) { bestpad = pad; NB = nbs[i]; }
-  }
-  const int COT = NB * 16;
-  const int COTP = (COT % 32 == 0) ? COT + 16 : COT;   // filter-slab pitch == 16 (mod 32): conflict-free A reads
   const int cin4 = (int)mpa_cdiv(Cin, 4) * 4;
   double bestcost = 1e300;
+  // cout blocking: all variants compete; the cost model charges padded couts, operand re-reads, and -- what decides
+  // small batches / small images -- the number of *rounds* the grid needs on 256 CUs (a grid of 2112 workgroups on 512
+  // resident slots costs 5 rounds, not 4.1)
+  const int nbs[4] = {1, 2, 4, 5};
   const int pbs[6] = {1, 2, 4, 6, 8, 12};
-  for (int pi = 0; pi < 6; ++pi) {
-    if ((pbs[pi] == 12 && NB > 2) || (pbs[pi] == 8 && NB > 4)) continue;   // accumulator budget
-    const int PB = pbs[pi], P = PB * 64;
-    for (int TH = 1; TH <= std::min(OH, P); ++TH) {
-      const int TWmax = std::min(OW, P / TH);
-      if (TWmax < 1) continue;
-      const int tx0 = (int)mpa_cdiv(OW, TWmax);
-      for (int txi = 0; txi < 10; ++txi) {
-        // candidate tile widths: the widest that fits, then progressively narrower ones (LDS-limited tall kernels)
-        const int tx = txi < 6 ? tx0 + txi : tx0 << (txi - 4);
-        if (tx > OW) break;
-        const int TW = (int)mpa_cdiv(OW, tx);
-        const int ty = (int)mpa_cdiv(OH, TH);
-        const int IH = (TH - 1) * sh + kh, IW = (TW - 1) * sw + kw;
-        for (int lwi = 0; lwi < 2; ++lwi) {
-          // row pitch == TW (mod 32) keeps pixel blocks that wrap a row conflict-free; fall back to the tight pitch.
-          // 16-byte LDS-DMA staging (quad): stride 1, W % 4 == 0, pitch % 4 == 0 and 3 spare columns for the
-          // 4-aligned window origin.
-          int LW = (lwi == 0 && sw == 1 && kw - 1 <= 29) ? TW + 32 : (IW | 1);
-          if (LW < IW) LW = IW | 1;
-          int quad = 0;
-          if (sw == 1 && W % 4 == 0) {
-            int lq = LW;
-            if (lq % 4 != 0 || lq < IW + 3) lq = (int)mpa_cdiv(std::max(LW, IW + 3), 4) * 4;
-            if (lwi == 1 || lq == LW) { LW = lq; quad = 1; }
-          }
-          const int CHP = round_mod(IH * LW, 32, 16);
-          int CK = 4;
-          while (CK < 32 && CK < cin4 && kw * (CK / 4) < 15) CK *= 2;
-          auto lds_words = [&](int ck) {
-            return mpa_cdiv((long)ck * CHP, 64) * 64 + 2 * (mpa_cdiv((long)kw * ck * COTP, 64) * 64);
-          };
-          while (CK > 4 && lds_words(CK) * 4 > FWD_LDS_BUDGET) CK /= 2;
-          const size_t lds = (size_t)lds_words(CK) * 4;
-          if ((long)lds > FWD_LDS_BUDGET) continue;
-          double cost = (double)ty * tx * P * (1.0 + 0.05 * IH * IW / P + 0.15 * (NB + PB) / (double)(NB * PB)) *
-                        (1.0 + 0.02 * lwi + 0.3 / (kw * (CK / 4))) * (quad ? 1.0 : 1.08);
-          if (cost < bestcost) {
-            bestcost = cost;
-            best = FwdPlan{NB, PB, TH, TW, ty, tx, CK, (int)mpa_cdiv(Cin, CK), IH, IW, LW, CHP, COT, COTP,
-                           (int)mpa_cdiv(Cout, COT), OH, OW, quad, lds, true};
+  for (int ni = 0; ni < 4; ++ni) {
+    const int NB = nbs[ni];
+    const int COT = NB * 16;
+    const int coTiles = (int)mpa_cdiv(Cout, COT);
+    if (ni > 0 && (long)coTiles * COT >= (long)mpa_cdiv(Cout, 16) * 16 + 32 && NB > 1) continue;   // too much cout padding
+    const int COTP = (COT % 32 == 0) ? COT + 16 : COT;   // filter-slab pitch == 16 (mod 32): conflict-free A reads
+    for (int pi = 0; pi < 6; ++pi) {
+      if ((pbs[pi] == 12 && NB > 2) || (pbs[pi] == 8 && NB > 4)) continue;   // accumulator budget
+      const int PB = pbs[pi], P = PB * 64;
+      for (int TH = 1; TH <= std::min(OH, P); ++TH) {
+        const int TWmax = std::min(OW, P / TH);
+        if (TWmax < 1) continue;
+        const int tx0 = (int)mpa_cdiv(OW, TWmax);
+        for (int txi = 0; txi < 10; ++txi) {
+          // candidate tile widths: the widest that fits, then progressively narrower ones (LDS-limited tall kernels)
+          const int tx = txi < 6 ? tx0 + txi : tx0 << (txi - 4);
+          if (tx > OW) break;
+          const int TW = (int)mpa_cdiv(OW, tx);
+          const int ty = (int)mpa_cdiv(OH, TH);
+          const int IH = (TH - 1) * sh + kh, IW = (TW - 1) * sw + kw;
+          for (int lwi = 0; lwi < 2; ++lwi) {
+            // row pitch == TW (mod 32) keeps pixel blocks that wrap a row conflict-free; fall back to the tight pitch.
+            // 16-byte LDS-DMA staging (quad): stride 1, W % 4 == 0, pitch % 4 == 0 and 3 spare columns for the
+            // 4-aligned window origin.
+            int LW = (lwi == 0 && sw == 1 && kw - 1 <= 29) ? TW + 32 : (IW | 1);
+            if (LW < IW) LW = IW | 1;
+            int quad = 0;
+            if (sw == 1 && W % 4 == 0) {
+              int lq = LW;
+              if (lq % 4 != 0 || lq < IW + 3) lq = (int)mpa_cdiv(std::max(LW, IW + 3), 4) * 4;
+              if (lwi == 1 || lq == LW) { LW = lq; quad = 1; }
+            }
+            const int CHP = round_mod(IH * LW, 32, 16);
+            int CK = 4;
+            while (CK < 32 && CK < cin4 && kw * (CK / 4) < 15) CK *= 2;
+            auto lds_words = [&](int ck) {
+              return mpa_cdiv((long)ck * CHP, 64) * 64 + 2 * (mpa_cdiv((long)kw * ck * COTP, 64) * 64);
+            };
+            while (CK > 4 && lds_words(CK) * 4 > 52 * 1024) CK /= 2;   // keep three workgroups per CU when the chunk allows
+            const size_t lds = (size_t)lds_words(CK) * 4;
+            if ((long)lds > FWD_LDS_BUDGET) continue;
+            // resident workgroups per CU: LDS and (estimated) VGPR limits
+            const int regs = NB * PB * 4 + 4 * (NB + PB) + 48;
+            const long bpc = std::max<long>(1, std::min<long>(std::min<long>(4, (160 * 1024) / (long)lds), 512 / regs));
+            const long blocks = (long)B * ty * tx * coTiles;
+            const long rounds = mpa_cdiv(blocks, 256 * bpc);
+            // cycles one workgroup needs when it shares each SIMD with bpc-1 others
+            const double per_block = (double)P * NB * (1.0 + 0.05 * IH * IW / P + 0.15 * (NB + PB) / (double)(NB * PB)) *
+                                     (1.0 + 0.02 * lwi + 0.3 / (kw * (CK / 4))) * (quad ? 1.0 : 1.08);
+            // large grids: throughput (blocks * per_block / 256 CUs); small grids: whole rounds
+            const double fill = (double)(TH * TW) / P;      // lanes doing useful work
+            // few rounds: whole rounds are paid (measured: 3.01 rounds cost as much as 3.32); many rounds: workgroups
+            // drift apart and only ~a third of a round is lost at the end
+            const double frac_rounds = (double)blocks / (256.0 * bpc);
+            const double eff_rounds = rounds <= 3 ? (double)rounds : frac_rounds + 0.35;
+            const double cost = eff_rounds * bpc * per_block * (1.0 + 0.25 * (1.0 - fill)) +
+                                1e-3 * blocks;
+            if (cost < bestcost) {
+              bestcost = cost;
+              best = FwdPlan{NB, PB, TH, TW, ty, tx, CK, (int)mpa_cdiv(Cin, CK), IH, IW, LW, CHP, COT, COTP, coTiles, OH, OW,
+                             quad, lds, true};
+            }
           }
         }
       }
@@ -244,7 +258,8 @@ __device__ __forceinline__ void glds_stage_x16(float* __restrict__ dst, const fl
     const int gy = y0 + iy, gx = x0a + 4 * q;
     const int ok = (int)(ch < cmax) & (int)(r < used4) & (int)((unsigned)gy < (unsigned)H) & (int)((unsigned)gx < (unsigned)W);
     const int off = (c0 + ch) * HW + gy * W + gx;
-    glds_quad(ok ? src + off : zsrc, dst + (long)base * 4);
+    if (base + lane < total4)       // the image is a multiple of 16 float4, not of 64: never spill into the next region
+      glds_quad(ok ? src + off : zsrc, dst + (long)base * 4);
     r += 256;
     while (r >= chp4) { r -= chp4; ch += 1; }
   }
@@ -269,7 +284,8 @@ __device__ __forceinline__ void glds_stage_dy16(float* __restrict__ dst, const f
     const int oy = y0 + py, ox = x0 + 4 * q;
     const int ok = (int)(co < cmax) & (int)(r < n4) & (int)(oy < OH) & (int)(ox < xlim);
     const int off = (c0 + co) * plane + oy * OW + ox;
-    glds_quad(ok ? src + off : zsrc, dst + (long)base * 4);
+    if (base + lane < total4)
+      glds_quad(ok ? src + off : zsrc, dst + (long)base * 4);
     r += 256;
     while (r >= dcp4) { r -= dcp4; co += 1; }
   }
@@ -918,11 +934,11 @@ int64_t mpa_conv2d_packed_floats(const mpa_conv_desc* d, int mode) {
   if (!d) return MPA_ERR_ARG;
   FwdPlan pl;
   if (mode == 0) {
-    pl = plan_fwd(d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw);
+    pl = plan_fwd(d->B, d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw);
   } else {
     BwdDataGeom g = bwd_data_geom(d);
     if (!g.ok) return MPA_ERR_UNSUPPORTED;
-    pl = plan_fwd(g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw);
+    pl = plan_fwd(d->B, g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw);
   }
   if (!pl.ok) return MPA_ERR_UNSUPPORTED;
   const int kh = d->kh, kw = (mode == 1 && bwd_data_geom(d).xphase) ? 1 : d->kw;
@@ -937,12 +953,12 @@ int mpa_conv2d_pack(const mpa_conv_desc* d, int mode, const float* w, float* w_p
   p.mode = mode; p.xphase = 0;
   FwdPlan pl;
   if (mode == 0) {
-    pl = plan_fwd(d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw);
+    pl = plan_fwd(d->B, d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw);
     p.CinP = d->Cin; p.CoutP = d->Cout; p.kh = d->kh; p.kw = d->kw;
   } else {
     BwdDataGeom g = bwd_data_geom(d);
     if (!g.ok) return MPA_ERR_UNSUPPORTED;
-    pl = plan_fwd(g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw);
+    pl = plan_fwd(d->B, g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw);
     p.CinP = g.Cin; p.CoutP = g.Cout; p.kh = g.kh; p.kw = g.kw; p.xphase = g.xphase ? 1 : 0;
   }
   if (!pl.ok) return MPA_ERR_UNSUPPORTED;
@@ -956,7 +972,7 @@ int mpa_conv2d_pack(const mpa_conv_desc* d, int mode, const float* w, float* w_p
 static int conv_fwd_impl(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
                          const float* x, const float* wp, const float* bias, float* y, int act, float slope,
                          long outBS, long outCS, int outRS, int outXmul, int outCdiv, hipStream_t s) {
-  FwdPlan pl = plan_fwd(Cin, H, W, Cout, kh, kw, sh, sw, ph, pw);
+  FwdPlan pl = plan_fwd(B, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw);
   if (!pl.ok) return MPA_ERR_UNSUPPORTED;
   ConvFwdParams p{};
   p.x = x; p.wp = wp; p.bias = bias; p.y = y;
@@ -1013,11 +1029,11 @@ int mpa_conv2d_describe_plan(const mpa_conv_desc* d, int mode, char* buf, int bu
     return MPA_OK;
   }
   FwdPlan f;
-  if (mode == 0) f = plan_fwd(d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw);
+  if (mode == 0) f = plan_fwd(d->B, d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw);
   else {
     BwdDataGeom g = bwd_data_geom(d);
     if (!g.ok) return MPA_ERR_UNSUPPORTED;
-    f = plan_fwd(g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw);
+    f = plan_fwd(d->B, g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw);
   }
   if (!f.ok) return MPA_ERR_UNSUPPORTED;
   snprintf(buf, buflen, "fwd<%d,%d> COT=%d coTiles=%d CK=%d chunks=%d tile=%dx%d tiles=%dx%d halo=%dx%d LW=%d quad=%d lds=%zuB",

@@ -78,7 +78,7 @@ def _packed(weight, desc, mode):
         if len(_pack_cache) > 1024:
             for k in [k for k, v in _pack_cache.items() if v[0]() is None]:
                 del _pack_cache[k]
-    key = (desc.key()[1:], mode)
+    key = (desc.key(), mode)          # the tiling (hence the packed layout) depends on the batch size too
     buf = ent[2].get(key)
     if buf is None:
         lib = _lib()
