@@ -434,8 +434,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
         float v = acc[nb][pb][r];
         if (p.bias) v += p.bias[co];
         v = mpa_apply_act(v, p.act, p.slope);
-        const int q = co / p.outCdiv, cc = co - q * p.outCdiv;
-        p.y[(long)b * p.outBS + (long)cc * p.outCS + (long)oy * p.outRS + (long)ox * p.outXmul + q] = v;
+        if (p.outCdiv >= p.Cout) {            // plain NCHW store (uniform branch)
+          p.y[(long)b * p.outBS + (long)co * p.outCS + (long)oy * p.outRS + ox] = v;
+        } else {                              // stride-(1,kw) backward-data: cout' = (dx phase, cin)
+          const int q = co / p.outCdiv, cc = co - q * p.outCdiv;
+          p.y[(long)b * p.outBS + (long)cc * p.outCS + (long)oy * p.outRS + (long)ox * p.outXmul + q] = v;
+        }
       }
     }
   }

@@ -12,7 +12,7 @@ for (B_, Cin, H, W, Cout) in [(256, 16, 75, 216, 128), (256, 128, 75, 216, 16), 
     x = torch.randn(B_, Cin, H, W, device=dev); w = torch.randn(Cout, Cin, 15, 15, device=dev); y = torch.empty(B_, Cout, H, W, device=dev)
     n = lib.mpa_conv2d_packed_floats(ctypes.byref(d), 0); wp = torch.empty(n, device=dev)
     lib.mpa_conv2d_pack(ctypes.byref(d), 0, P(w), P(wp), None)
-    for dbg in ('0', '1', '3'):
+    for dbg in ('0', '4', '5'):
         os.environ['MPA_DEBUG_FWD'] = dbg
         ts = []
         for it in range(3):
