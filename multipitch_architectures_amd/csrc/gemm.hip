@@ -198,7 +198,7 @@ extern "C" int mpa_gemm(const float* A, int64_t lda_m, int64_t lda_k, const floa
   else {
     // ... or, for small outputs with a long reduction (weight gradients: K = batch*positions), the largest tile and a
     // split of K over blockIdx.z with atomic accumulation (order of the fp32 adds is not fixed; no activation)
-    variant = (M >= 128 && N >= 128) ? 0 : 3;
+    variant = (M >= 128 && N >= 128 && b128 >= 64) ? 0 : 3;     // tiny outputs: 64x64 tiles keep more CUs busy
     blocks = variant == 0 ? b128 : b64;
   }
   int splits = 1;
