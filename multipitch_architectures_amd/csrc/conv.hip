@@ -417,7 +417,41 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
     }
   }
 
-  // epilogue: lane holds 4 consecutive couts (rows) of one pixel (column)
+  // epilogue: lane holds 4 consecutive couts (rows) of one pixel (column).
+  // Wide path (NB*PB > 16, plain NCHW target, TW % 4 == 0, OW % 4 == 0): every 16x16 accumulator tile is transposed
+  // through a wave-private LDS patch so that a lane owns 4 consecutive pixels of one cout and writes one 16-byte store
+  // -- 4x fewer store instructions (measured: the 128 dword stores per lane of <4,8> cost 6.4 % of the workgroup's life).
+  if (NB * PB > 16 && p.outCdiv >= p.Cout && (p.TW & 3) == 0 && (p.OW & 3) == 0 && p.act != MPA_ACT_SIGMOID) {
+    __syncthreads();                                  // the main loop's LDS images are dead now
+    float* patch = lds + wave * (16 * 20);            // [cout 16][pixel 16 (+4 pad)]
+    const int co_l = lane >> 2, quad = lane & 3;      // after the transpose: lane -> (cout row, 4-pixel group)
+    const float neg_scale = p.act == MPA_ACT_NONE ? 1.f : (p.act == MPA_ACT_RELU ? 0.f : p.slope);
+    float* yb = p.y + (long)b * p.outBS;
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+      const int pix4 = (wave * PB + pb) * 16 + quad * 4;
+      const int pc = pix4 < npix ? pix4 : 0;
+      const int py = pc / p.TW, px = pc - py * p.TW;
+      const int oy = oy0 + py, ox = ox0 + px;
+      const bool ok4 = pix4 < npix && oy < p.OH && ox < p.OW;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) patch[(kq * 4 + r) * 20 + l16] = acc[nb][pb][r];
+        __builtin_amdgcn_wave_barrier();
+        float4 v = *reinterpret_cast<const float4*>(patch + co_l * 20 + quad * 4);
+        __builtin_amdgcn_wave_barrier();
+        const int co = cot * p.COT + nb * 16 + co_l;
+        const float bs = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
+        v.x += bs; v.y += bs; v.z += bs; v.w += bs;
+        v.x = v.x >= 0.f ? v.x : v.x * neg_scale; v.y = v.y >= 0.f ? v.y : v.y * neg_scale;
+        v.z = v.z >= 0.f ? v.z : v.z * neg_scale; v.w = v.w >= 0.f ? v.w : v.w * neg_scale;
+        if (ok4 && co < p.Cout)
+          *reinterpret_cast<float4*>(yb + (long)co * p.outCS + (long)oy * p.outRS + ox) = v;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int pb = 0; pb < PB; ++pb) {
     const int pix = (wave * PB + pb) * 16 + l16;
