@@ -51,6 +51,49 @@ def cpu_baseline(config, frames, sample_batch=8, steps=2):
             f"(torch-CPU restatement oracle/restate.py, {dt:.2f} s/step)"}
 
 
+def patch_extraction_probe(batch, with_cpu):
+    """`dataset_context` windows + the training augmentations, one launch per batch from a resident
+    recording (not part of the timed train step, whose inputs are already in HBM).  HBM-bound: 4 B read + 4 B written
+    per output element."""
+    from multipitch_architectures_amd.data_loaders import dataset_context
+    from multipitch_architectures_amd.synth import synth_file
+    params = {"context": 75, "stride": 50, "compression": 10, "aug:transpsemitones": 5, "aug:randomeq": 20,
+              "aug:noisestd": 1e-4, "aug:tuning": True}                    # exp180d...py:38-45
+    inputs, targets = synth_file(frames=50 * batch + 100, seed=11)
+    ds = dataset_context(inputs, targets, params)
+    idx = list(range(batch))
+    for _ in range(3):
+        ds.batch(idx)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    reps = 20
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev[0].record()
+    for _ in range(reps):
+        X, y = ds.batch(idx)
+    ev[1].record()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    ms = ev[0].elapsed_time(ev[1]) / reps
+    nbytes = 8.0 * X.numel()
+    res = {"patches_per_s": batch / wall, "launch_ms": ms, "batch": batch, "bound": "hbm",
+           "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+           "frac": nbytes / (ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_patch": nbytes / batch,
+           "note": "device time per launch incl. the host's index-table upload; wall-clock rate in patches_per_s"}
+    if with_cpu:
+        from oracle import restate_data as RD                     # checker timed as the CPU baseline, never shipped
+        ti, tt = torch.from_numpy(inputs), torch.from_numpy(targets)
+        torch.set_num_threads(1)
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 3.0:
+            RD.context_patch(ti, tt, params, n % batch)
+            n += 1
+        res["cpu_baseline"] = {"value": n / (time.perf_counter() - t0), "unit": "patches/s", "cores": 1, "kind": "port",
+                               "sample": f"{n} patches, one thread (the reference uses 16 DataLoader workers)"}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,6 +223,8 @@ def main():
             out["step_mfma_frac"] = step_tflops / (PEAK_FP32_MFMA_TFLOPS * world)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, args.frames)
+        if world == 1:
+            out["patch_extraction"] = patch_extraction_probe(B_loc, not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

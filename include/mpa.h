@@ -163,6 +163,32 @@ int mpa_adamw_step(float* const* params, const float* const* grads, float* const
                    const int64_t* sizes, int ntensors, int64_t max_size, double lr, double beta1, double beta2,
                    double eps, double weight_decay, int step, void* stream);
 
+/* ------------------------------------------------------------------ patch extraction + augmentation
+ * replaces libdl/data_loaders/hcqt_datasets.py:67-141 (dataset_context.__getitem__) and :199-289
+ * (dataset_context_segm.__getitem__ without time scaling), for B patches per launch.  Recordings are resident
+ * (n_harm, T_file, n_bins) fp32 tensors, targets (T_file, n_out) fp32.                                          */
+enum { MPA_CTX_EQ = 1, MPA_CTX_NOISE = 2, MPA_CTX_LOG = 4, MPA_CTX_TUNE = 8, MPA_CTX_TRANSP = 16,
+       MPA_CTX_SEGM_TARGETS = 32 /* dataset_context_segm's 4-D target: transposition clears frames, not bins (:273-277) */ };
+typedef struct mpa_context_desc {
+  int32_t n_harm;     /* 6 */
+  int32_t n_bins;     /* 216 */
+  int32_t frames;     /* frames per patch: 2*(context/2) + seglength */
+  int32_t n_out;      /* target bins: 72 (pitch) or 12 (pitch class: circular roll) */
+  int32_t seglength;  /* target rows per patch (1 for dataset_context) */
+  int32_t flags;      /* MPA_CTX_* stages to apply, in the reference's order */
+  float compression;  /* gamma of log(1 + gamma*x) */
+  float noisestd;     /* 'aug:noisestd' */
+} mpa_context_desc;
+/* src[b]: device address of (harmonic 0, first frame of window b, bin 0); chan_stride[b]: elements between harmonics;
+ * tgt[b]: device address of the first target row of window b.  aug: (B,4) int32 = alpha, beta ('aug:randomeq'
+ * parabola, already accepted by the reference's non-negativity test), tuning shift in half bins (-2..2), transposition
+ * in semitones.  n1 (B,n_harm,frames,n_bins), n2 (B,n_harm,frames), n3 (B,n_harm,frames,15): explicit Gaussian draws
+ * (already scaled by their std) for parity tests; NULL = counter-based generator seeded by `seed`.
+ * X: (B,n_harm,frames,n_bins), y: (B,1,seglength,n_out).                                                        */
+int mpa_context_batch(const mpa_context_desc* d, int B, const uint64_t* src, const int64_t* chan_stride,
+                      const uint64_t* tgt, const int32_t* aug, const float* n1, const float* n2, const float* n3,
+                      uint64_t seed, float* X, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

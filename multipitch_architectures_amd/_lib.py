@@ -32,6 +32,14 @@ class ConvDesc(ctypes.Structure):
 
 
 _P = c_void_p
+class ContextDesc(ctypes.Structure):
+    """mirror of struct mpa_context_desc"""
+    _fields_ = [(n, ctypes.c_int32) for n in ("n_harm", "n_bins", "frames", "n_out", "seglength", "flags")] + \
+               [("compression", ctypes.c_float), ("noisestd", ctypes.c_float)]
+
+
+CTX_EQ, CTX_NOISE, CTX_LOG, CTX_TUNE, CTX_TRANSP, CTX_SEGM_TARGETS = 1, 2, 4, 8, 16, 32
+
 _D = ctypes.POINTER(ConvDesc)
 
 # name -> (restype, argtypes); must list every symbol include/mpa.h declares
@@ -76,6 +84,7 @@ SIGNATURES = {
     "mpa_bce_fwd": (c_int, [_P, _P, _P, c_int64, _P]),
     "mpa_bce_bwd": (c_int, [_P, _P, _P, c_int64, _P, _P]),
     "mpa_ce_fwd_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, _P]),
+    "mpa_context_batch": (c_int, [ctypes.POINTER(ContextDesc), c_int, _P, _P, _P, _P, _P, _P, _P, ctypes.c_uint64, _P, _P, _P]),
     "mpa_adamw_step": (c_int, [_P, _P, _P, _P, _P, c_int, c_int64, c_double, c_double, c_double, c_double, c_double, c_int, _P]),
 }
 

@@ -1,0 +1,147 @@
+// Patch extraction + augmentation on resident recordings.
+// Replaces libdl/data_loaders/hcqt_datasets.py:67-141 (dataset_context.__getitem__) and the time-scaling-free part of
+// :199-289 (dataset_context_segm.__getitem__) for a whole batch at once: the recordings stay in HBM as
+// (n_harm, T_file, n_bins) fp32, one launch gathers B windows and applies EQ -> noise+abs -> log compression ->
+// tuning shift -> transposition in registers.  HBM-bound: 4 B read + 4 B written per output element.
+#include "mpa_common.h"
+#include <math.h>
+
+namespace {
+
+struct CtxParams {
+  int n_harm, n_bins, frames, n_out, seglength, flags, B;
+  float compression, noisestd;
+  int eq_off[16];
+  const uint64_t* src;            // [B] device address of (harmonic 0, first frame of the window, bin 0)
+  const int64_t* chan_stride;     // [B] elements between harmonics of that recording
+  const uint64_t* tgt;            // [B] device address of the first target row
+  const int32_t* aug;             // [B][4] alpha, beta, tune2 (half bins), transp (semitones); nullable = all zero
+  const float *n1, *n2, *n3;      // explicit N(0,1)*std draws (tests) or null = counter-based generator
+  uint64_t seed;
+  float* X;
+  float* y;
+};
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+// one N(0,1) value per (seed, stream, index): Box-Muller on two 24-bit uniforms of a splitmix64 counter hash
+__device__ __forceinline__ float gauss(uint64_t seed, uint64_t stream, uint64_t idx) {
+  const uint64_t z = mix64(seed + 0x9E3779B97F4A7C15ull * (idx * 4 + stream + 1));
+  const float u1 = ((float)(z >> 40) + 1.0f) * (1.0f / 16777216.0f);          // (0,1]
+  const float u2 = (float)((z >> 16) & 0xFFFFFF) * (1.0f / 16777216.0f);      // [0,1)
+  return sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
+}
+
+// value of bin g of the row after EQ, noise+abs and compression (hcqt_datasets.py:83-106)
+__device__ __forceinline__ float base_value(const CtxParams& p, const float* row, const float* n1row, uint64_t ridx, int g,
+                                            float eq_scale, int eq_centre) {
+  float v = row[g];
+  if (p.flags & MPA_CTX_EQ) {
+    const int d = g - eq_centre;
+    v = (1.0f - eq_scale * (float)(d * d)) * v;
+  }
+  if (p.flags & MPA_CTX_NOISE) {
+    const float n = n1row ? n1row[g] : p.noisestd * gauss(p.seed, 0, ridx * (uint64_t)p.n_bins + g);
+    v = fabsf(v + n);
+  }
+  if (p.flags & MPA_CTX_LOG) v = logf(1.0f + p.compression * v);
+  return v;
+}
+
+// one block per (patch, harmonic, frame) row; thread = output bin
+__global__ __launch_bounds__(256) void context_rows_kernel(CtxParams p) {
+  const long ridx = blockIdx.x;                       // (b*n_harm + h)*frames + t
+  const int t = (int)(ridx % p.frames);
+  const int h = (int)((ridx / p.frames) % p.n_harm);
+  const int b = (int)(ridx / ((long)p.frames * p.n_harm));
+  const float* row = (const float*)p.src[b] + (long)h * p.chan_stride[b] + (long)t * p.n_bins;
+  int alpha = 0, beta = 0, tune2 = 0, transp = 0;
+  if (p.aug) {
+    alpha = p.aug[b * 4 + 0]; beta = p.aug[b * 4 + 1]; tune2 = p.aug[b * 4 + 2]; transp = p.aug[b * 4 + 3];
+  }
+  if (!(p.flags & MPA_CTX_TUNE)) tune2 = 0;
+  if (!(p.flags & MPA_CTX_TRANSP)) transp = 0;
+  const float eq_scale = 2e-6f * (float)alpha;
+  const int eq_centre = beta - p.eq_off[h];
+  const float* n1row = p.n1 ? p.n1 + ridx * p.n_bins : nullptr;
+  float* out = p.X + ridx * p.n_bins;
+  for (int f = threadIdx.x; f < p.n_bins; f += 256) {
+    float v;
+    const int g = f - 3 * transp;                     // bin of the tuned row that the +-semitone roll moves to f (:128)
+    if (g < 0 || g >= p.n_bins) {                     // exposed by the roll: |N(0,1e-4)| (:131-135)
+      const int j = transp > 0 ? f : f - (p.n_bins + 3 * transp);
+      const float n = p.n3 ? p.n3[ridx * 15 + j] : 1e-4f * gauss(p.seed, 2, ridx * 16 + j);
+      v = fabsf(n);
+    } else if ((tune2 > 0 && g == 0) || (tune2 < 0 && g == p.n_bins - 1)) {   // edge exposed by the tuning shift (:121-124)
+      const float n = p.n2 ? p.n2[ridx] : 1e-4f * gauss(p.seed, 1, ridx);
+      v = fabsf(n);
+    } else if (tune2 == 1) {                          // +0.5 bin: mean with the lower neighbour (:114-115)
+      v = (base_value(p, row, n1row, ridx, g - 1, eq_scale, eq_centre) + base_value(p, row, n1row, ridx, g, eq_scale, eq_centre)) / 2;
+    } else if (tune2 == -1) {                         // -0.5 bin (:117-118)
+      v = (base_value(p, row, n1row, ridx, g, eq_scale, eq_centre) + base_value(p, row, n1row, ridx, g + 1, eq_scale, eq_centre)) / 2;
+    } else {                                          // 0 or +-1 bin roll (:120)
+      v = base_value(p, row, n1row, ridx, g - tune2 / 2, eq_scale, eq_centre);
+    }
+    out[f] = v;
+  }
+}
+
+// targets: (B, 1, seglength, n_out); rolled by the transposition with zero fill (circular for 12 pitch classes, :129-137)
+__global__ __launch_bounds__(256) void context_targets_kernel(CtxParams p) {
+  const long n = (long)p.B * p.seglength * p.n_out;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int k = (int)(i % p.n_out);
+    const int s = (int)((i / p.n_out) % p.seglength);
+    const int b = (int)(i / ((long)p.n_out * p.seglength));
+    const int transp = (p.aug && (p.flags & MPA_CTX_TRANSP)) ? p.aug[b * 4 + 3] : 0;
+    const float* trow = (const float*)p.tgt[b] + (long)s * p.n_out;
+    int src = k - transp;
+    float v;
+    if (p.flags & MPA_CTX_SEGM_TARGETS) {
+      // dataset_context_segm's target is 4-D (1,1,seglength,n_out), so the reference's `y_trans[:, :, :transp] = 0`
+      // (:273,276) clears |transp| *frames*, and the bins keep torch.roll's circular wrap -- reproduced, not fixed
+      src %= p.n_out;
+      if (src < 0) src += p.n_out;
+      const bool cleared = p.n_out != 12 && ((transp > 0 && s < transp) || (transp < 0 && s >= p.seglength + transp));
+      v = cleared ? 0.f : trow[src];
+    } else if (p.n_out == 12) {
+      src %= 12;
+      if (src < 0) src += 12;
+      v = trow[src];
+    } else {
+      v = (src >= 0 && src < p.n_out) ? trow[src] : 0.f;
+    }
+    p.y[i] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int mpa_context_batch(const mpa_context_desc* d, int B, const uint64_t* src, const int64_t* chan_stride,
+                                 const uint64_t* tgt, const int32_t* aug, const float* n1, const float* n2,
+                                 const float* n3, uint64_t seed, float* X, float* y, void* stream) {
+  if (!d || !src || !chan_stride || !tgt || !X || !y) return MPA_ERR_ARG;
+  if (d->n_harm < 1 || d->n_harm > 16 || d->n_bins < 1 || d->frames < 1 || d->n_out < 1 || d->seglength < 1 || B < 0)
+    return MPA_ERR_ARG;
+  if ((d->flags & (MPA_CTX_EQ | MPA_CTX_TUNE | MPA_CTX_TRANSP)) && !aug) return MPA_ERR_ARG;
+  if ((d->flags & MPA_CTX_TRANSP) && d->n_bins < 16) return MPA_ERR_ARG;
+  if (B == 0) return MPA_OK;
+  CtxParams p;
+  p.n_harm = d->n_harm; p.n_bins = d->n_bins; p.frames = d->frames; p.n_out = d->n_out; p.seglength = d->seglength;
+  p.flags = d->flags; p.B = B; p.compression = d->compression; p.noisestd = d->noisestd;
+  for (int h = 0; h < 16; ++h) p.eq_off[h] = h == 0 ? -36 : (int)(36.0 * log2((double)h));   // hcqt_datasets.py:90-93
+  p.src = src; p.chan_stride = chan_stride; p.tgt = tgt; p.aug = aug; p.n1 = n1; p.n2 = n2; p.n3 = n3; p.seed = seed;
+  p.X = X; p.y = y;
+  const long rows = (long)B * d->n_harm * d->frames;
+  if (rows > 0x7fffffffL) return MPA_ERR_ARG;
+  MPA_LAUNCH(context_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, p);
+  int rc = mpa_launch_status();
+  if (rc != MPA_OK) return rc;
+  const long n = (long)B * d->seglength * d->n_out;
+  MPA_LAUNCH(context_targets_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0,
+             (hipStream_t)stream, p);
+  return mpa_launch_status();
+}

@@ -1,0 +1,203 @@
+"""GPU-resident replacement of ``libdl/data_loaders/hcqt_datasets.py`` ``dataset_context`` (:10-141) and
+``dataset_context_segm`` (:144-289): same constructor, ``len()`` and parameter dictionary; the recording lives in HBM
+and patches are cut *and* augmented by one HIP launch per batch (``mpa_context_batch``) instead of by 16 DataLoader
+workers (exp180d...py:54-57).
+
+Differences, all deliberate:
+* ``__getitem__`` returns device tensors; ``batch(indices)`` is the fast path, ``ContextLoader`` the
+  ``ConcatDataset`` + ``DataLoader(batch_size, shuffle)`` equivalent (with rank sharding for data-parallel runs).
+* Random decisions (EQ parabola, tuning shift, transposition) are drawn on the host from a numpy PCG64 stream, noise by
+  a counter-based generator in the kernel -- same distributions as the reference, not the same torch-CPU stream.  Pass
+  ``draws=...`` to ``batch`` to dictate them (used by the parity tests).
+* ``'aug:scalingfactor'`` (time scaling, ``dataset_context_segm`` only) and ``'aug:smooth_len'`` are not built:
+  requesting them raises.
+There is no CPU path: construction fails without the HIP library and a GPU.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+
+N_BINS = 216
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _eq_min_ok(alpha, beta, n_harm):
+    """vectorised form of the reference's accept test ``min(filtmat) >= 0`` (hcqt_datasets.py:84-97): the parabola's
+    minimum over bins 0..215 is at the bin farthest from its centre; evaluated in float32 like the reference."""
+    ok = np.ones(alpha.shape, dtype=bool)
+    scale = np.float32(2e-6) * alpha.astype(np.float32)
+    for h in range(n_harm):
+        off = -36 if h == 0 else int(36 * np.log2(h))
+        c = beta - off
+        far = np.maximum(np.abs(0 - c), np.abs(N_BINS - 1 - c)).astype(np.int64)
+        ok &= (np.float32(1) - scale * (far * far).astype(np.float32)) >= 0
+    return ok
+
+
+class dataset_context:
+    """``dataset_context(inputs, targets, params)`` -- hcqt_datasets.py:30-60.
+
+    inputs: (n_harm, T, 216) tensor/array of *uncompressed* HCQT magnitudes, targets: (T, n_out)."""
+
+    _segm = False
+
+    def __init__(self, inputs, targets, params, device="cuda:0", seed=0):
+        L.load()                                        # fail loudly: no CPU path
+        if not torch.cuda.is_available():
+            raise RuntimeError("dataset_context needs a GPU: the recordings are kept resident in HBM")
+        self.device = torch.device(device)
+        self.inputs = torch.as_tensor(inputs).to(self.device, torch.float32).contiguous()
+        self.targets = torch.as_tensor(targets).to(self.device, torch.float32).contiguous()
+        if self.inputs.dim() != 3 or self.targets.dim() != 2 or self.inputs.shape[1] != self.targets.shape[0]:
+            raise RuntimeError(f"expected inputs (n_harm,T,n_bins) and targets (T,n_out); got "
+                               f"{tuple(self.inputs.shape)} / {tuple(self.targets.shape)}")
+        self.context = params["context"]
+        self.stride = params["stride"]
+        self.compression = params["compression"]
+        self.seglength = params["seglength"] if self._segm else 1
+        self.targettype = params.get("targettype", "pitch_class")
+        self.transposition = params.get("aug:transpsemitones")
+        self.scalingfactor = params.get("aug:scalingfactor")
+        self.randomeq = params.get("aug:randomeq")
+        self.noisestd = params.get("aug:noisestd")
+        self.tuning = params.get("aug:tuning")
+        if self.scalingfactor:
+            raise NotImplementedError("'aug:scalingfactor' (time scaling) is not built")
+        if params.get("aug:smooth_len", 0) > 1:
+            raise NotImplementedError("'aug:smooth_len' (target smoothing) is not built")
+        if (self.randomeq or self.transposition) and self.inputs.shape[2] != N_BINS:
+            raise RuntimeError("the augmentations assume 216 bins (3 per semitone), as the reference does")
+        if self.transposition and self.transposition > 5:
+            raise RuntimeError("'aug:transpsemitones' > 5 is not supported")
+        self.rng = np.random.Generator(np.random.PCG64(seed))
+        self._calls = 0
+        self._seed = seed
+        flags = 0
+        flags |= L.CTX_EQ if self.randomeq else 0
+        flags |= L.CTX_NOISE if self.noisestd else 0
+        flags |= L.CTX_LOG if self.compression is not None else 0
+        flags |= L.CTX_TUNE if self.tuning else 0
+        flags |= L.CTX_TRANSP if self.transposition else 0
+        flags |= L.CTX_SEGM_TARGETS if self._segm else 0
+        self.frames = 2 * (self.context // 2) + self.seglength
+        self.desc = L.ContextDesc(self.inputs.shape[0], self.inputs.shape[2], self.frames, self.targets.shape[1],
+                                  self.seglength, flags, float(self.compression or 0.0), float(self.noisestd or 0.0))
+
+    def __len__(self):
+        if self._segm:                                  # :195-197
+            return (self.inputs.shape[1] - self.context - self.seglength + self.stride) // self.stride
+        return (self.inputs.shape[1] - self.context) // self.stride   # :62-64
+
+    # ------------------------------------------------------------------ random decisions (host side)
+    def draw(self, n):
+        """(n,4) int32: alpha, beta, tune2, transp -- distributions of hcqt_datasets.py:83-97,109,127."""
+        aug = np.zeros((n, 4), dtype=np.int32)
+        if self.randomeq:
+            todo = np.arange(n)
+            while todo.size:
+                a = self.rng.integers(1, self.randomeq + 1, todo.size)
+                b = self.rng.integers(0, N_BINS, todo.size)
+                ok = _eq_min_ok(a, b, self.inputs.shape[0])
+                aug[todo[ok], 0], aug[todo[ok], 1] = a[ok], b[ok]
+                todo = todo[~ok]
+        if self.tuning:
+            aug[:, 2] = self.rng.integers(-2, 3, n)
+        if self.transposition:
+            aug[:, 3] = self.rng.integers(-self.transposition, self.transposition + 1, n)
+        return aug
+
+    # ------------------------------------------------------------------ addressing (host side, bounds-checked)
+    def addresses(self, indices):
+        idx = np.asarray(indices, dtype=np.int64).reshape(-1)
+        start = idx * self.stride
+        # like the reference, an index past len() is served as long as its window lies inside the recording; anything
+        # else would read out of bounds on the device and is refused here
+        if idx.size and (idx.min() < 0 or start.max() + self.frames > self.inputs.shape[1]):
+            raise IndexError(f"patch window outside the recording (len() = {len(self)}, frames = {self.inputs.shape[1]})")
+        src = self.inputs.data_ptr() + start * (self.inputs.shape[2] * 4)
+        tgt = self.targets.data_ptr() + (start + self.context // 2) * (self.targets.shape[1] * 4)
+        cs = np.full(idx.shape, self.inputs.shape[1] * self.inputs.shape[2], dtype=np.int64)
+        return src.astype(np.uint64), cs, tgt.astype(np.uint64)
+
+    def batch(self, indices, draws=None):
+        return gather([(self, indices)], draws=draws)
+
+    def __getitem__(self, index):
+        X, y = self.batch([index])
+        return X[0], y[0]
+
+
+class dataset_context_segm(dataset_context):
+    """``dataset_context_segm`` (hcqt_datasets.py:144-289) without time scaling: ``seglength`` target frames per patch."""
+    _segm = True
+
+
+def gather(parts, draws=None):
+    """One launch for patches taken from several resident recordings.
+    parts: [(dataset, indices)], all datasets sharing the parameter dictionary (the first one's is used).
+    draws: optional dict(aug=(B,4) int, n1=..., n2=..., n3=... float32 tensors or None) to dictate the randomness."""
+    ds0 = parts[0][0]
+    src, cs, tgt = (np.concatenate(a) for a in zip(*[ds.addresses(ix) for ds, ix in parts]))
+    B = int(src.size)
+    dev = ds0.device
+    aug = np.asarray(draws["aug"], dtype=np.int32).reshape(B, 4) if draws is not None else ds0.draw(B)
+    table = torch.from_numpy(np.concatenate([src.view(np.int64), cs, tgt.view(np.int64)])).to(dev, non_blocking=True)
+    aug_d = torch.from_numpy(aug).to(dev, non_blocking=True)
+    X = torch.empty((B, ds0.desc.n_harm, ds0.frames, ds0.desc.n_bins), dtype=torch.float32, device=dev)
+    y = torch.empty((B, 1, ds0.seglength, ds0.desc.n_out), dtype=torch.float32, device=dev)
+    n1 = n2 = n3 = None
+    if draws is not None:
+        n1, n2, n3 = (None if draws.get(k) is None else draws[k].to(dev, torch.float32).contiguous()
+                      for k in ("n1", "n2", "n3"))
+        if n1 is not None: assert tuple(n1.shape) == tuple(X.shape)
+        if n2 is not None: assert n2.numel() == B * ds0.desc.n_harm * ds0.frames
+        if n3 is not None: assert n3.numel() == B * ds0.desc.n_harm * ds0.frames * 15
+    ds0._calls += 1
+    seed = (ds0._seed * 0x9E3779B97F4A7C15 + ds0._calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    off = table.data_ptr()
+    rc = L.load().mpa_context_batch(ctypes.byref(ds0.desc), B, ctypes.c_void_p(off), ctypes.c_void_p(off + 8 * B),
+                                    ctypes.c_void_p(off + 16 * B), _p(aug_d), _p(n1), _p(n2), _p(n3),
+                                    ctypes.c_uint64(seed), _p(X), _p(y),
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    L.check(rc, "mpa_context_batch")
+    X._mpa_keepalive = (table, aug_d)      # the launch is asynchronous w.r.t. the host
+    if ds0._segm:                          # the reference's per-item target is (1,1,seglength,n_out) there (:208)
+        y = y.view(B, 1, 1, ds0.seglength, ds0.desc.n_out)
+    return X, y
+
+
+class ContextLoader:
+    """``DataLoader(ConcatDataset(datasets), batch_size, shuffle)`` (exp180d...py:287-288) over resident recordings.
+    ``rank``/``world`` shard every global batch like ``parallel.shard_range``."""
+
+    def __init__(self, datasets, batch_size, shuffle=False, seed=0, rank=0, world=1, drop_last=False):
+        self.datasets = list(datasets)
+        self.batch_size, self.shuffle, self.drop_last = batch_size, shuffle, drop_last
+        self.rank, self.world = rank, world
+        self.rng = np.random.Generator(np.random.PCG64(seed))
+        lens = np.array([len(d) for d in self.datasets], dtype=np.int64)
+        self.file_of = np.repeat(np.arange(len(self.datasets)), lens)
+        self.local = np.concatenate([np.arange(n) for n in lens]) if lens.size else np.zeros(0, np.int64)
+
+    def __len__(self):
+        n = self.file_of.size
+        return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
+
+    def __iter__(self):
+        order = self.rng.permutation(self.file_of.size) if self.shuffle else np.arange(self.file_of.size)
+        for k in range(len(self)):
+            sel = order[k * self.batch_size:(k + 1) * self.batch_size]
+            per = -(-sel.size // self.world)
+            sel = sel[self.rank * per:(self.rank + 1) * per]
+            if sel.size == 0:
+                continue
+            parts = []
+            for f in np.unique(self.file_of[sel]):           # group by recording, keep the batch order inside a group
+                parts.append((self.datasets[f], self.local[sel[self.file_of[sel] == f]]))
+            yield gather(parts)

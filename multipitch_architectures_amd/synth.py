@@ -67,3 +67,13 @@ def det_fill(state_dict, seed: int = 0):
             v = g.normal(0.0, np.sqrt(2.0 / fan_in), size=shape)
         out[key] = torch.from_numpy(np.asarray(v, dtype=np.float32)).to(ref.dtype)
     return out
+
+
+def synth_file(frames=400, n_harm=6, n_bins=216, n_bins_out=72, seed=77):
+    """One synthetic "recording": raw (uncompressed) HCQT magnitudes (n_harm, frames, n_bins) float32 ~ Gamma(0.3, 0.05)
+    and a binary pitch activity matrix (frames, n_bins_out) float32 ~ Bernoulli(0.04) -- the shapes
+    ``dataset_context`` receives after the transpose in exp126a...py:262-263."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    inputs = rng.gamma(0.3, 0.05, size=(n_harm, frames, n_bins)).astype(np.float32)
+    targets = (rng.random((frames, n_bins_out)) < 0.04).astype(np.float32)
+    return inputs, targets

@@ -1,0 +1,80 @@
+"""ORACLE tooling -- generates tests/golden/data_*.npz by importing the reference's ``dataset_context`` /
+``dataset_context_segm`` (``libdl/data_loaders/hcqt_datasets.py``).  Build container only.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_goldens_data.py
+
+``hcqt_datasets.py:6`` imports ``torchvision.transforms`` (never used by the two classes); torchvision is not in the
+image, so an *empty* module object stands in for that import line only.  The file tensors are synthetic
+(``synth.synth_file``); the random augmentation is pinned by ``torch.manual_seed(seed)`` immediately before each
+``__getitem__`` -- the oracle (oracle/restate_data.py) consumes the generator in the same order.
+
+Stored per case: the parameter dict (JSON), seed, index, the full target ``y``, and of ``X`` a strided sample (every
+11th value) plus sum / abs-sum / max -- data only.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(1, "/root/reference")
+sys.dont_write_bytecode = True
+
+_tv = types.ModuleType("torchvision")
+_tv.transforms = types.ModuleType("torchvision.transforms")
+sys.modules.setdefault("torchvision", _tv)
+sys.modules.setdefault("torchvision.transforms", _tv.transforms)
+
+from libdl.data_loaders.hcqt_datasets import dataset_context, dataset_context_segm  # noqa: E402  (the reference)
+
+from multipitch_architectures_amd.synth import synth_file  # noqa: E402
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+TRAIN = {"context": 75, "stride": 50, "compression": 10, "aug:transpsemitones": 5, "aug:randomeq": 20,
+         "aug:noisestd": 1e-4, "aug:tuning": True}                       # exp180d...py:38-45
+VAL = {"context": 75, "stride": 50, "compression": 10}                    # :46-49
+TEST = {"context": 75, "stride": 1, "compression": 10}                    # :50-53
+
+CASES = [("val", VAL, 72, [(0, 0), (3, 0)]),
+         ("test", TEST, 72, [(0, 0), (101, 0), (324, 0)]),
+         ("train", TRAIN, 72, [(i % 7, 100 + i) for i in range(24)]),      # 24 seeds: covers every tuning shift / sign
+         ("train_pc", TRAIN, 12, [(i % 7, 300 + i) for i in range(6)]),    # pitch-class targets (circular roll)
+         ("nocomp_eq", {"context": 75, "stride": 25, "compression": None, "aug:randomeq": 20}, 72,
+          [(i, 400 + i) for i in range(3)]),
+         ("tune_only", {"context": 75, "stride": 10, "compression": 10, "aug:tuning": True}, 72,
+          [(i, 500 + i) for i in range(8)]),
+         ("segm", dict(TRAIN, seglength=100, stride=35), 72, [(i % 3, 600 + i) for i in range(8)]),
+         ("ctx25", {"context": 25, "stride": 5, "compression": 1.0, "aug:transpsemitones": 2, "aug:noisestd": 1e-3},
+          72, [(i, 700 + i) for i in range(6)])]
+
+
+def main():
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    for name, params, n_out, items in CASES:
+        inputs, targets = synth_file(frames=400, n_bins_out=n_out, seed=77)
+        cls = dataset_context_segm if "seglength" in params else dataset_context
+        out = {"params": np.array(json.dumps(params)), "n_out": np.array(n_out),
+               "items": np.array(items, dtype=np.int64)}
+        for k, (index, seed) in enumerate(items):
+            # fresh tensors per item: with float32 inputs and noise-without-EQ the reference adds the noise into the
+            # file tensor itself (hcqt_datasets.py:75,101) -- not part of the restated behaviour
+            ds = cls(torch.from_numpy(inputs.copy()), torch.from_numpy(targets.copy()), dict(params))
+            out["len"] = np.array(len(ds))
+            torch.manual_seed(seed)
+            X, y = ds[index]
+            X = np.asarray(X, dtype=np.float32)
+            out[f"{k}.shape"] = np.array(X.shape)
+            out[f"{k}.xs"] = X.ravel()[::11].copy()
+            out[f"{k}.stats"] = np.array([X.astype(np.float64).sum(), np.abs(X).astype(np.float64).sum(), X.max()])
+            out[f"{k}.y"] = np.asarray(y, dtype=np.float32)
+        np.savez_compressed(os.path.join(GOLDEN_DIR, f"data_{name}.npz"), **out)
+        print("wrote", name, len(items), "items; len(ds) =", len(ds))
+
+
+if __name__ == "__main__":
+    main()
