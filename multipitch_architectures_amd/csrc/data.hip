@@ -22,41 +22,53 @@ struct CtxParams {
   float* y;
 };
 
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
+// 32-bit avalanche hash (two multiply-xorshift rounds)
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
 }
-// one N(0,1) value per (seed, stream, index): Box-Muller on two 24-bit uniforms of a splitmix64 counter hash
-__device__ __forceinline__ float gauss(uint64_t seed, uint64_t stream, uint64_t idx) {
-  const uint64_t z = mix64(seed + 0x9E3779B97F4A7C15ull * (idx * 4 + stream + 1));
-  const float u1 = ((float)(z >> 40) + 1.0f) * (1.0f / 16777216.0f);          // (0,1]
-  const float u2 = (float)((z >> 16) & 0xFFFFFF) * (1.0f / 16777216.0f);      // [0,1)
-  return sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
+// two independent N(0,1) values per (seed, stream, index): Box-Muller (both branches) on two 24-bit uniforms obtained
+// from a counter hash; fast intrinsics (~1e-6 abs error) are ample for augmentation noise
+__device__ __forceinline__ float2 gauss2(uint64_t seed, uint32_t stream, uint64_t idx) {
+  const uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+  const uint32_t k = hash32((uint32_t)seed ^ (stream * 0x9E3779B9u) ^ hash32(hi + (uint32_t)(seed >> 32)));
+  const uint32_t a = hash32(lo ^ k), b = hash32(lo + 0x632BE5ABu + (k << 1 | 1u));
+  const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);           // (0,1]
+  const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);                    // [0,1)
+  const float rad = sqrtf(-2.0f * __logf(u1));
+  float sn, cs;
+  __sincosf(6.2831853f * u2, &sn, &cs);
+  return make_float2(rad * cs, rad * sn);
 }
+__device__ __forceinline__ float gauss(uint64_t seed, uint32_t stream, uint64_t idx) { return gauss2(seed, stream, idx).x; }
 
-// value of bin g of the row after EQ, noise+abs and compression (hcqt_datasets.py:83-106)
-__device__ __forceinline__ float base_value(const CtxParams& p, const float* row, const float* n1row, uint64_t ridx, int g,
-                                            float eq_scale, int eq_centre) {
-  float v = row[g];
+// stages EQ -> noise+abs -> compression of one bin (hcqt_datasets.py:83-106); `n` = the (already scaled) noise draw
+__device__ __forceinline__ float base_value(const CtxParams& p, float v, float n, int g, float eq_scale, int eq_centre) {
   if (p.flags & MPA_CTX_EQ) {
     const int d = g - eq_centre;
     v = (1.0f - eq_scale * (float)(d * d)) * v;
   }
-  if (p.flags & MPA_CTX_NOISE) {
-    const float n = n1row ? n1row[g] : p.noisestd * gauss(p.seed, 0, ridx * (uint64_t)p.n_bins + g);
-    v = fabsf(v + n);
-  }
+  if (p.flags & MPA_CTX_NOISE) v = fabsf(v + n);
   if (p.flags & MPA_CTX_LOG) v = logf(1.0f + p.compression * v);
   return v;
 }
 
-// one block per (patch, harmonic, frame) row; thread = output bin
-__global__ __launch_bounds__(256) void context_rows_kernel(CtxParams p) {
-  const long ridx = blockIdx.x;                       // (b*n_harm + h)*frames + t
-  const int t = (int)(ridx % p.frames);
-  const int h = (int)((ridx / p.frames) % p.n_harm);
-  const int b = (int)(ridx / ((long)p.frames * p.n_harm));
+// CTX_ROWS (patch, harmonic, frame) rows per block.  Phase 1 puts the compressed row (stages EQ..log) into LDS once,
+// phase 2 forms the tuning shift / transposition from it -- the +-0.5-bin average needs two neighbours per output and
+// the Gaussian generator is the expensive part, so nothing is evaluated twice.
+constexpr int CTX_ROWS = 4;
+constexpr int CTX_MAXBINS = 256;
+__global__ __launch_bounds__(256) void context_rows_kernel(CtxParams p, int nrows) {
+  __shared__ float base_s[CTX_ROWS][CTX_MAXBINS];
+  const int r = threadIdx.x >> 6, lane = threadIdx.x & 63;            // one wave per row: the row decode is wave-uniform
+  const int ridx = blockIdx.x * CTX_ROWS + r;                         // (b*n_harm + h)*frames + t
+  if (ridx >= nrows) return;                                          // whole wave; no block-wide barrier below
+  const int t = ridx % p.frames;
+  const int bh = ridx / p.frames;
+  const int h = bh % p.n_harm;
+  const int b = bh / p.n_harm;
   const float* row = (const float*)p.src[b] + (long)h * p.chan_stride[b] + (long)t * p.n_bins;
   int alpha = 0, beta = 0, tune2 = 0, transp = 0;
   if (p.aug) {
@@ -66,24 +78,42 @@ __global__ __launch_bounds__(256) void context_rows_kernel(CtxParams p) {
   if (!(p.flags & MPA_CTX_TRANSP)) transp = 0;
   const float eq_scale = 2e-6f * (float)alpha;
   const int eq_centre = beta - p.eq_off[h];
-  const float* n1row = p.n1 ? p.n1 + ridx * p.n_bins : nullptr;
-  float* out = p.X + ridx * p.n_bins;
-  for (int f = threadIdx.x; f < p.n_bins; f += 256) {
+  const float* n1row = p.n1 ? p.n1 + (long)ridx * p.n_bins : nullptr;
+  float* base = base_s[r];
+  for (int g = lane; g < p.n_bins; g += 128) {                        // bins g and g+64 share one Box-Muller pair
+    const int g2 = g + 64;
+    float2 n = make_float2(0.f, 0.f);
+    if (p.flags & MPA_CTX_NOISE) {
+      if (n1row) {
+        n.x = n1row[g];
+        if (g2 < p.n_bins) n.y = n1row[g2];
+      } else {
+        n = gauss2(p.seed, 0, (uint64_t)ridx * 256 + g);
+        n.x *= p.noisestd; n.y *= p.noisestd;
+      }
+    }
+    base[g] = base_value(p, row[g], n.x, g, eq_scale, eq_centre);
+    if (g2 < p.n_bins) base[g2] = base_value(p, row[g2], n.y, g2, eq_scale, eq_centre);
+  }
+  __builtin_amdgcn_wave_barrier();                                    // LDS row is private to this wave
+  __builtin_amdgcn_s_waitcnt(0xc07f);                                 // lgkmcnt(0): the row is written
+  float* out = p.X + (long)ridx * p.n_bins;
+  for (int f = lane; f < p.n_bins; f += 64) {
     float v;
     const int g = f - 3 * transp;                     // bin of the tuned row that the +-semitone roll moves to f (:128)
     if (g < 0 || g >= p.n_bins) {                     // exposed by the roll: |N(0,1e-4)| (:131-135)
       const int j = transp > 0 ? f : f - (p.n_bins + 3 * transp);
-      const float n = p.n3 ? p.n3[ridx * 15 + j] : 1e-4f * gauss(p.seed, 2, ridx * 16 + j);
+      const float n = p.n3 ? p.n3[(long)ridx * 15 + j] : 1e-4f * gauss(p.seed, 2, (uint64_t)ridx * 16 + j);
       v = fabsf(n);
     } else if ((tune2 > 0 && g == 0) || (tune2 < 0 && g == p.n_bins - 1)) {   // edge exposed by the tuning shift (:121-124)
-      const float n = p.n2 ? p.n2[ridx] : 1e-4f * gauss(p.seed, 1, ridx);
+      const float n = p.n2 ? p.n2[ridx] : 1e-4f * gauss(p.seed, 1, (uint64_t)ridx);
       v = fabsf(n);
     } else if (tune2 == 1) {                          // +0.5 bin: mean with the lower neighbour (:114-115)
-      v = (base_value(p, row, n1row, ridx, g - 1, eq_scale, eq_centre) + base_value(p, row, n1row, ridx, g, eq_scale, eq_centre)) / 2;
+      v = (base[g - 1] + base[g]) / 2;
     } else if (tune2 == -1) {                         // -0.5 bin (:117-118)
-      v = (base_value(p, row, n1row, ridx, g, eq_scale, eq_centre) + base_value(p, row, n1row, ridx, g + 1, eq_scale, eq_centre)) / 2;
+      v = (base[g] + base[g + 1]) / 2;
     } else {                                          // 0 or +-1 bin roll (:120)
-      v = base_value(p, row, n1row, ridx, g - tune2 / 2, eq_scale, eq_centre);
+      v = base[g - tune2 / 2];
     }
     out[f] = v;
   }
@@ -124,7 +154,7 @@ extern "C" int mpa_context_batch(const mpa_context_desc* d, int B, const uint64_
                                  const uint64_t* tgt, const int32_t* aug, const float* n1, const float* n2,
                                  const float* n3, uint64_t seed, float* X, float* y, void* stream) {
   if (!d || !src || !chan_stride || !tgt || !X || !y) return MPA_ERR_ARG;
-  if (d->n_harm < 1 || d->n_harm > 16 || d->n_bins < 1 || d->frames < 1 || d->n_out < 1 || d->seglength < 1 || B < 0)
+  if (d->n_harm < 1 || d->n_harm > 16 || d->n_bins < 1 || d->n_bins > CTX_MAXBINS || d->frames < 1 || d->n_out < 1 || d->seglength < 1 || B < 0)
     return MPA_ERR_ARG;
   if ((d->flags & (MPA_CTX_EQ | MPA_CTX_TUNE | MPA_CTX_TRANSP)) && !aug) return MPA_ERR_ARG;
   if ((d->flags & MPA_CTX_TRANSP) && d->n_bins < 16) return MPA_ERR_ARG;
@@ -137,7 +167,8 @@ extern "C" int mpa_context_batch(const mpa_context_desc* d, int B, const uint64_
   p.X = X; p.y = y;
   const long rows = (long)B * d->n_harm * d->frames;
   if (rows > 0x7fffffffL) return MPA_ERR_ARG;
-  MPA_LAUNCH(context_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, p);
+  MPA_LAUNCH(context_rows_kernel, dim3((unsigned)((rows + CTX_ROWS - 1) / CTX_ROWS)), dim3(256), 0, (hipStream_t)stream,
+             p, (int)rows);
   int rc = mpa_launch_status();
   if (rc != MPA_OK) return rc;
   const long n = (long)B * d->seglength * d->n_out;
