@@ -107,6 +107,32 @@ def patch_extraction_probe(batch, with_cpu):
     return res
 
 
+def eval_measures_probe(with_cpu, n_frames=20000):
+    """the 11 evaluation measures of one recording (about 7.7 min of audio at 43 Hz), predictions already
+    on the device.  HBM-bound in principle (8 B per (frame, bin) read once per pass) but launch-latency dominated at
+    this size: 1.44 M scores."""
+    from multipitch_architectures_amd.metrics import MEASURES, calculate_eval_measures
+    from multipitch_architectures_amd.synth import synth_eval_pair
+    targ, pred = synth_eval_pair(n_frames=n_frames, seed=3)
+    t, p = torch.from_numpy(targ).cuda(), torch.from_numpy(pred).cuda()
+    calculate_eval_measures(t, p, MEASURES, threshold=0.4)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        got = calculate_eval_measures(t, p, MEASURES, threshold=0.4)       # ends with a device->host copy of 16 doubles
+    dt = (time.perf_counter() - t0) / reps
+    res = {"frames": n_frames, "bins": 72, "ms_per_recording": dt * 1e3, "frames_per_s": n_frames / dt,
+           "f_measure": got["f_measure"]}
+    if with_cpu:
+        from oracle import restate_metrics as RM                  # checker timed as the CPU baseline, never shipped
+        t0 = time.perf_counter()
+        RM.all_measures(targ, pred, threshold=0.4)
+        res["cpu_baseline"] = {"value": n_frames / (time.perf_counter() - t0), "unit": "frames/s", "cores": 1,
+                               "kind": "port", "sample": f"one recording of {n_frames} frames (numpy + scikit-learn)"}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -238,6 +264,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.config, args.frames)
         if world == 1:
             out["patch_extraction"] = patch_extraction_probe(B_loc, not args.no_cpu_baseline)
+            out["eval_measures"] = eval_measures_probe(not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

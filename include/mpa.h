@@ -189,6 +189,17 @@ int mpa_context_batch(const mpa_context_desc* d, int B, const uint64_t* src, con
                       const uint64_t* tgt, const int32_t* aug, const float* n1, const float* n2, const float* n3,
                       uint64_t seed, float* X, float* y, void* stream);
 
+/* ------------------------------------------------------------------ evaluation measures
+ * replaces libdl/metrics/eval_metrics.py:8-116 (calculate_single_measure; the 11 measures of exp180d...py:150-151)
+ * incl. libfmp/c5/c5s2_chord_rec_template.py:238-261 and libfmp/c3/c3s1_post_processing.py:60-68.
+ * targ, pred: (n_frames, n_bins) fp32 device arrays of one recording; arithmetic in float64 like the reference.
+ * out (device, 16 doubles): [0..10] precision, recall, f_measure, cosine_sim, binary_crossentropy,
+ * euclidean_distance, binary_accuracy, soft_accuracy, accum_energy, roc_auc_measure, average_precision_score;
+ * [11..13] TP, FP, FN; [14..15] number of positive / negative targets (roc_auc is not finite if either is 0).   */
+int64_t mpa_eval_measures_workspace(int64_t n_frames, int n_bins);
+int mpa_eval_measures(const float* targ, const float* pred, int64_t n_frames, int n_bins, double threshold,
+                      double* out, void* ws, int64_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

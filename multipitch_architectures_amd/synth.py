@@ -77,3 +77,18 @@ def synth_file(frames=400, n_harm=6, n_bins=216, n_bins_out=72, seed=77):
     inputs = rng.gamma(0.3, 0.05, size=(n_harm, frames, n_bins)).astype(np.float32)
     targets = (rng.random((frames, n_bins_out)) < 0.04).astype(np.float32)
     return inputs, targets
+
+
+def synth_eval_pair(n_frames=500, n_bins=72, seed=5, quant=None, silent_frames=0, scale=1.0):
+    """Targets/predictions for the evaluation measures: Bernoulli(0.04) targets (float32 0/1) and predictions that are
+    a noisy logistic function of them (float32 in (0,1)).  ``quant`` rounds predictions to that many levels (ties for
+    the ranking measures), ``silent_frames`` leading frames get all-zero targets, ``scale`` < 1 shrinks predictions
+    (``scale=0.3`` keeps everything below the 0.4 threshold)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    targ = (rng.random((n_frames, n_bins)) < 0.04).astype(np.float32)
+    targ[:silent_frames] = 0
+    z = 3.0 * targ - 2.0 + rng.normal(0, 1.2, size=targ.shape)
+    pred = (scale / (1.0 + np.exp(-z))).astype(np.float32)
+    if quant:
+        pred = (np.round(pred * quant) / quant).astype(np.float32)
+    return targ, pred

@@ -318,11 +318,27 @@ MODELS = {f.__name__: f for f in (
 
 
 # --------------------------------------------------------------------------- losses / optimizer (caller side, a11)
+class _BCEMean(torch.autograd.Function):
+    """torch.nn.BCELoss(reduction='mean'): forward with the log terms clamped at -100, backward
+    (p - y) / max(p (1 - p), 1e-12) / N  (ATen's binary_cross_entropy_backward).  Differentiating the clamped logs
+    instead would give 0 * inf = NaN as soon as a probability saturates to exactly 0 or 1."""
+
+    @staticmethod
+    def forward(ctx, p, y):
+        ctx.save_for_backward(p, y)
+        lp = torch.clamp(torch.log(p), min=-100.0)
+        lq = torch.clamp(torch.log(1 - p), min=-100.0)
+        return -(y * lp + (1 - y) * lq).mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        p, y = ctx.saved_tensors
+        return g * (p - y) / torch.clamp((1 - p) * p, min=1e-12) / p.numel(), None
+
+
 def bce_loss(p, y):
-    """torch.nn.BCELoss(reduction='mean') (exp126a...py:87): log terms clamped at -100."""
-    lp = torch.clamp(torch.log(p), min=-100.0)
-    lq = torch.clamp(torch.log(1 - p), min=-100.0)
-    return -(y * lp + (1 - y) * lq).mean()
+    """torch.nn.BCELoss(reduction='mean') (exp126a...py:87)."""
+    return _BCEMean.apply(p, y)
 
 
 def punet_loss(y_pred, n_pred, y):

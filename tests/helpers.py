@@ -18,6 +18,8 @@ def golden_cases():
     out = []
     for f in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))):
         base = os.path.basename(f)[:-4]
+        if "__" not in base:            # data_*.npz / metrics_*.npz belong to the section-8(f) tests
+            continue
         name, rest = base.split("__")
         B, T = rest.split("_")
         out.append((name.replace("_", ":", 1), int(B[1:]), int(T[1:])))
