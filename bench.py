@@ -8,6 +8,7 @@ Headline workload (BASELINE.json configs[3]): SAUnet:L (exp180d), global batch 2
 (local batch 256/N), data-parallel with RCCL gradient all-reduce.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -202,6 +203,11 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # Python's generation-2 collector walks every live object (modules, parameters, autograd graph) and costs ~70 ms
+    # when it triggers -- two steps' worth at local batch 32.  Move what exists now to the permanent generation so that
+    # collections inside the timed region only look at objects created by the steps themselves.
+    gc.collect()
+    gc.freeze()
     # live roofline probe: the dominant kernel = the widest 15x15 forward conv (upconv4.double_conv.4: 16->128)
     dom = max((m for m in model.modules() if isinstance(m, nn_models.layers.Conv2d)),
               key=lambda m: m.in_channels * m.out_channels * m.kernel_size[0] * m.kernel_size[1] *

@@ -183,28 +183,24 @@ extern "C" int mpa_gemm(const float* A, int64_t lda_m, int64_t lda_k, const floa
   if (!A || !Bm || !C || M <= 0 || N <= 0 || K <= 0) return MPA_ERR_ARG;
   GemmParams p{A, Bm, bias, C, (long)lda_m, (long)lda_k, (long)ldb_k, (long)ldb_n, (long)ldc, M, N, K, accumulate, act, K};
   hipStream_t s = (hipStream_t)stream;
-  // largest tile that still gives every CU (256) a couple of workgroups ...
-  const long b128 = mpa_cdiv(M, 128) * mpa_cdiv(N, 128);
-  const long b12864 = mpa_cdiv(M, 128) * mpa_cdiv(N, 64);
-  const long b64128 = mpa_cdiv(M, 64) * mpa_cdiv(N, 128);
-  const long b64 = mpa_cdiv(M, 64) * mpa_cdiv(N, 64);
-  int variant;            // 0: 128x128, 1: 128x64, 2: 64x128, 3: 64x64
-  long blocks;
-  if (b128 >= 384) { variant = 0; blocks = b128; }
-  else if (b12864 >= 384 && M >= N) { variant = 1; blocks = b12864; }
-  else if (b64128 >= 384) { variant = 2; blocks = b64128; }
-  else if (b12864 >= 384) { variant = 1; blocks = b12864; }
-  else if (b64 >= 256) { variant = 3; blocks = b64; }
-  else {
-    // ... or, for small outputs with a long reduction (weight gradients: K = batch*positions), the largest tile and a
-    // split of K over blockIdx.z with atomic accumulation (order of the fp32 adds is not fixed; no activation)
-    variant = (M >= 128 && N >= 128 && b128 >= 64) ? 0 : 3;     // tiny outputs: 64x64 tiles keep more CUs busy
-    blocks = variant == 0 ? b128 : b64;
-  }
-  int splits = 1;
-  if (blocks < 256 && act == MPA_ACT_NONE && K >= 1024) {
-    splits = (int)std::min<long>(mpa_cdiv(768, blocks), K / 256);
-    if (splits < 1) splits = 1;
+  // Pick tile and K-split by a small cost model: whole "rounds" of workgroups over 256 CUs x 2 resident workgroups,
+  // each costing (its K extent + a fixed prologue/epilogue) x tile area / tile efficiency (the 64-wide tiles issue one
+  // LDS operand read per MFMA, the 128x128 tile one per two).  Splitting K (atomic accumulation, no activation, order
+  // of the fp32 adds not fixed) is what keeps the big tile usable for tall-skinny products such as the MLP's second
+  // layer (13312x128x8192) and the weight gradients (K = batch*positions).
+  static const int TM[4] = {128, 128, 64, 64}, TN[4] = {128, 64, 128, 64};
+  static const double EFF[4] = {1.0, 0.8, 0.8, 0.55};
+  int variant = 3, splits = 1;
+  double best = 1e300;
+  for (int v = 0; v < 4; ++v) {
+    const long blocks = mpa_cdiv(M, TM[v]) * mpa_cdiv(N, TN[v]);
+    // padding waste of partial tiles is paid in full
+    for (int sp = 1; sp <= 32; sp *= 2) {
+      if (sp > 1 && (act != MPA_ACT_NONE || K / sp < 256)) break;
+      const double rounds = (double)mpa_cdiv(blocks * sp, 512);
+      const double cost = rounds * ((double)mpa_cdiv(K, sp) + 96.0) * TM[v] * TN[v] / EFF[v] * (sp > 1 ? 1.03 : 1.0);
+      if (cost < best) { best = cost; variant = v; splits = sp; }
+    }
   }
   if (splits > 1) {
     p.kchunk = (int)(mpa_cdiv(mpa_cdiv(K, splits), BK) * BK);

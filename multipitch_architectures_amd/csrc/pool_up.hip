@@ -4,16 +4,87 @@
 
 namespace {
 
+// one wave per output row (plane, oy): the row decode is wave-uniform (no per-element 64-bit divisions), lanes run along
+// the row so loads and stores are contiguous
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                          int32_t* __restrict__ idx, long planes, int H, int W, int OH,
+                                                          int32_t* __restrict__ idx, long rows, int H, int W, int OH,
                                                           int OW, int kh, int kw, int sh, int sw, int ph, int pw) {
-  const long total = planes * OH * OW;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int ox = (int)(i % OW);
-    const long r = i / OW;
-    const int oy = (int)(r % OH);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
     const long pl = r / OH;
+    const int oy = (int)(r - pl * OH);
     const float* xp = x + pl * H * W;
+    const int y0 = oy * sh - ph;
+    const int dy_lo = y0 < 0 ? -y0 : 0, dy_hi = (y0 + kh > H ? H - y0 : kh);
+    for (int ox = lane; ox < OW; ox += 64) {
+      const int x0 = ox * sw - pw;
+      float best = -INFINITY;
+      int bi = -1;
+      for (int dy = dy_lo; dy < dy_hi; ++dy) {
+        const int iy = y0 + dy;
+        for (int dx = 0; dx < kw; ++dx) {
+          const int ix = x0 + dx;
+          if (ix < 0 || ix >= W) continue;
+          const float v = xp[iy * W + ix];
+          if (bi < 0 || v > best || v != v) { best = v; bi = iy * W + ix; }   // first maximum wins; NaN propagates
+        }
+      }
+      y[r * OW + ox] = best;
+      if (idx) idx[r * OW + ox] = bi;
+    }
+  }
+}
+
+// gather form: every input element sums dy of the windows whose recorded argmax it is (deterministic, no atomics);
+// one wave per input row (plane, iy)
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ idx,
+                                                          float* __restrict__ dx, long rows, int H, int W, int OH,
+                                                          int OW, int kh, int kw, int sh, int sw, int ph, int pw) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+    const long pl = r / H;
+    const int iy = (int)(r - pl * H);
+    // windows oy with oy*sh - ph <= iy <= oy*sh - ph + kh - 1
+    int oy_lo = (iy + ph - kh + 1 + sh - 1);
+    oy_lo = oy_lo <= 0 ? 0 : oy_lo / sh;
+    int oy_hi = (iy + ph) / sh;
+    if (oy_hi > OH - 1) oy_hi = OH - 1;
+    const long ob = pl * OH * OW;
+    for (int ix = lane; ix < W; ix += 64) {
+      const int me = iy * W + ix;
+      int ox_lo = (ix + pw - kw + 1 + sw - 1);
+      ox_lo = ox_lo <= 0 ? 0 : ox_lo / sw;
+      int ox_hi = (ix + pw) / sw;
+      if (ox_hi > OW - 1) ox_hi = OW - 1;
+      float s = 0.f;
+      for (int oy = oy_lo; oy <= oy_hi; ++oy)
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+          const long o = ob + (long)oy * OW + ox;
+          if (idx[o] == me) s += dy[o];
+        }
+      dx[r * W + ix] = s;
+    }
+  }
+}
+
+// Plane-in-LDS variants: one workgroup owns one (b, c) plane, stages it in LDS with contiguous loads and forms every
+// window from LDS -- each input element crosses HBM once even for tall windows (the head's 13x1 stride-1 pool re-reads
+// every row 13 times otherwise).
+__global__ __launch_bounds__(256) void maxpool_fwd_plane_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                int32_t* __restrict__ idx, int H, int W, int OH, int OW,
+                                                                int kh, int kw, int sh, int sw, int ph, int pw) {
+  extern __shared__ float plane[];
+  const long pl = blockIdx.x;
+  const float* xp = x + pl * H * W;
+  const int n_in = H * W, n_out = OH * OW;
+  if ((n_in & 3) == 0) {
+    for (int i = threadIdx.x * 4; i < n_in; i += 1024) *(float4*)(plane + i) = *(const float4*)(xp + i);
+  } else {
+    for (int i = threadIdx.x; i < n_in; i += 256) plane[i] = xp[i];
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < n_out; o += 256) {
+    const int oy = o / OW, ox = o - oy * OW;
     const int y0 = oy * sh - ph, x0 = ox * sw - pw;
     float best = -INFINITY;
     int bi = -1;
@@ -23,27 +94,30 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
       for (int dx = 0; dx < kw; ++dx) {
         const int ix = x0 + dx;
         if (ix < 0 || ix >= W) continue;
-        const float v = xp[iy * W + ix];
+        const float v = plane[iy * W + ix];
         if (bi < 0 || v > best || v != v) { best = v; bi = iy * W + ix; }   // first maximum wins; NaN propagates
       }
     }
-    y[i] = best;
-    if (idx) idx[i] = bi;
+    y[pl * n_out + o] = best;
+    if (idx) idx[pl * n_out + o] = bi;
   }
 }
 
-// gather form: every input element sums dy of the windows whose recorded argmax it is (deterministic, no atomics)
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ idx,
-                                                          float* __restrict__ dx, long planes, int H, int W, int OH,
-                                                          int OW, int kh, int kw, int sh, int sw, int ph, int pw) {
-  const long total = planes * H * W;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int ix = (int)(i % W);
-    const long r = i / W;
-    const int iy = (int)(r % H);
-    const long pl = r / H;
-    const int me = iy * W + ix;
-    // windows oy with oy*sh - ph <= iy <= oy*sh - ph + kh - 1
+__global__ __launch_bounds__(256) void maxpool_bwd_plane_kernel(const float* __restrict__ dy, const int32_t* __restrict__ idx,
+                                                                float* __restrict__ dx, int H, int W, int OH, int OW,
+                                                                int kh, int kw, int sh, int sw, int ph, int pw) {
+  extern __shared__ float plane[];
+  const int n_in = H * W, n_out = OH * OW;
+  float* g = plane;                         // dy plane
+  int32_t* am = (int32_t*)(plane + n_out);  // argmax plane
+  const long pl = blockIdx.x;
+  for (int o = threadIdx.x; o < n_out; o += 256) {
+    g[o] = dy[pl * n_out + o];
+    am[o] = idx[pl * n_out + o];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_in; i += 256) {
+    const int iy = i / W, ix = i - iy * W;
     int oy_lo = (iy + ph - kh + 1 + sh - 1);
     oy_lo = oy_lo <= 0 ? 0 : oy_lo / sh;
     int oy_hi = (iy + ph) / sh;
@@ -53,13 +127,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
     int ox_hi = (ix + pw) / sw;
     if (ox_hi > OW - 1) ox_hi = OW - 1;
     float s = 0.f;
-    const long ob = pl * OH * OW;
     for (int oy = oy_lo; oy <= oy_hi; ++oy)
       for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-        const long o = ob + (long)oy * OW + ox;
-        if (idx[o] == me) s += dy[o];
+        const int o = oy * OW + ox;
+        if (am[o] == i) s += g[o];
       }
-    dx[i] = s;
+    dx[pl * n_in + i] = s;
   }
 }
 
@@ -74,67 +147,81 @@ __device__ __forceinline__ void bilin_src(int dst, int n_in, int n_out, int& i0,
   l = src - (float)i0;
 }
 
+// one wave per output row (b, c, y)
 __global__ __launch_bounds__(256) void upcat_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ skip,
                                                         float* __restrict__ out, int B, int C1, int H1, int W1, int Cs,
                                                         int Hs, int Ws) {
   const int Ct = Cs + C1;
-  const long total = (long)B * Ct * Hs * Ws;
+  const long rows = (long)B * Ct * Hs;
   const int UH = 2 * H1, UW = 2 * W1;
   const int padT = (Hs - UH) / 2, padL = (Ws - UW) / 2;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int x = (int)(i % Ws);
-    long r = i / Ws;
-    const int y = (int)(r % Hs);
-    r /= Hs;
-    const int c = (int)(r % Ct);
-    const int b = (int)(r / Ct);
-    float v;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+    const long bc = r / Hs;
+    const int y = (int)(r - bc * Hs);
+    const int b = (int)(bc / Ct);
+    const int c = (int)(bc - (long)b * Ct);
+    float* orow = out + r * Ws;
     if (c < Cs) {
-      v = skip[(((long)b * Cs + c) * Hs + y) * Ws + x];
-    } else {
-      const int uy = y - padT, ux = x - padL;
-      if (uy < 0 || uy >= UH || ux < 0 || ux >= UW) {
-        v = 0.f;
-      } else {
-        int y0, y1, x0, x1i;
-        float ly, lx;
-        bilin_src(uy, H1, UH, y0, y1, ly);
-        bilin_src(ux, W1, UW, x0, x1i, lx);
-        const float* p = x1 + ((long)b * C1 + (c - Cs)) * H1 * W1;
-        const float hy = 1.f - ly, hx = 1.f - lx;
-        v = hy * (hx * p[y0 * W1 + x0] + lx * p[y0 * W1 + x1i]) + ly * (hx * p[y1 * W1 + x0] + lx * p[y1 * W1 + x1i]);
-      }
+      const float* srow = skip + (((long)b * Cs + c) * Hs + y) * Ws;
+      for (int x = lane; x < Ws; x += 64) orow[x] = srow[x];
+      continue;
     }
-    out[i] = v;
+    const int uy = y - padT;
+    if (uy < 0 || uy >= UH) {
+      for (int x = lane; x < Ws; x += 64) orow[x] = 0.f;
+      continue;
+    }
+    int y0, y1;
+    float ly;
+    bilin_src(uy, H1, UH, y0, y1, ly);
+    const float hy = 1.f - ly;
+    const float* p0 = x1 + (((long)b * C1 + (c - Cs)) * H1 + y0) * W1;
+    const float* p1 = x1 + (((long)b * C1 + (c - Cs)) * H1 + y1) * W1;
+    for (int x = lane; x < Ws; x += 64) {
+      const int ux = x - padL;
+      float v = 0.f;
+      if (ux >= 0 && ux < UW) {
+        int x0, x1i;
+        float lx;
+        bilin_src(ux, W1, UW, x0, x1i, lx);
+        const float hx = 1.f - lx;
+        v = hy * (hx * p0[x0] + lx * p0[x1i]) + ly * (hx * p1[x0] + lx * p1[x1i]);
+      }
+      orow[x] = v;
+    }
   }
 }
 
-// dskip = dout[:, :Cs]; dx1[i,j] = sum over upsampled positions that read (i,j)
+// dskip = dout[:, :Cs]; dx1[i,j] = sum over upsampled positions that read (i,j).  One wave per row: first the
+// B*Cs*Hs skip rows, then the B*C1*H1 rows of dx1.
 __global__ __launch_bounds__(256) void upcat_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx1,
                                                         float* __restrict__ dskip, int B, int C1, int H1, int W1, int Cs,
                                                         int Hs, int Ws) {
   const int Ct = Cs + C1;
   const int UH = 2 * H1, UW = 2 * W1;
   const int padT = (Hs - UH) / 2, padL = (Ws - UW) / 2;
-  const long nskip = (long)B * Cs * Hs * Ws, nx1 = (long)B * C1 * H1 * W1;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nskip + nx1; i += (long)gridDim.x * 256) {
-    if (i < nskip) {
-      const long plane = Hs * (long)Ws;
-      const long b = i / (Cs * plane), rem = i - b * (Cs * plane);
-      dskip[i] = dout[b * Ct * plane + rem];
+  const long rskip = (long)B * Cs * Hs, rx1 = (long)B * C1 * H1;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (long r = (long)blockIdx.x * 4 + wave; r < rskip + rx1; r += (long)gridDim.x * 4) {
+    if (r < rskip) {
+      const long b = r / ((long)Cs * Hs), rem = r - b * ((long)Cs * Hs);
+      const float* src = dout + (b * Ct * Hs + rem) * Ws;
+      float* dst = dskip + r * Ws;
+      for (int x = lane; x < Ws; x += 64) dst[x] = src[x];
       continue;
     }
-    const long k = i - nskip;
-    const int j = (int)(k % W1);
-    long r = k / W1;
-    const int ii = (int)(r % H1);
-    r /= H1;
-    const int c = (int)(r % C1);
-    const int b = (int)(r / C1);
+    const long k = r - rskip;
+    const long bc = k / H1;
+    const int ii = (int)(k - bc * H1);
+    const int b = (int)(bc / C1);
+    const int c = (int)(bc - (long)b * C1);
     const float* dp = dout + (((long)b * Ct + Cs + c) * Hs) * Ws;
-    float s = 0.f;
+    // rows of the upsampled image that read source row ii, with their weights (wave-uniform)
+    float wys[6];
+    int oys[6];
+    int nwy = 0;
     const int uy_lo = max(0, 2 * ii - 2), uy_hi = min(UH - 1, 2 * ii + 3);
-    const int ux_lo = max(0, 2 * j - 2), ux_hi = min(UW - 1, 2 * j + 3);
     for (int uy = uy_lo; uy <= uy_hi; ++uy) {
       int y0, y1;
       float ly;
@@ -142,9 +229,13 @@ __global__ __launch_bounds__(256) void upcat_bwd_kernel(const float* __restrict_
       float wy = 0.f;
       if (y0 == ii) wy += 1.f - ly;
       if (y1 == ii) wy += ly;
-      if (wy == 0.f) continue;
       const int oy = uy + padT;
-      if (oy < 0 || oy >= Hs) continue;
+      if (wy == 0.f || oy < 0 || oy >= Hs) continue;
+      wys[nwy] = wy; oys[nwy] = oy; ++nwy;
+    }
+    for (int j = lane; j < W1; j += 64) {
+      float s = 0.f;
+      const int ux_lo = max(0, 2 * j - 2), ux_hi = min(UW - 1, 2 * j + 3);
       for (int ux = ux_lo; ux <= ux_hi; ++ux) {
         int x0, x1i;
         float lx;
@@ -152,16 +243,17 @@ __global__ __launch_bounds__(256) void upcat_bwd_kernel(const float* __restrict_
         float wx = 0.f;
         if (x0 == j) wx += 1.f - lx;
         if (x1i == j) wx += lx;
-        if (wx == 0.f) continue;
         const int ox = ux + padL;
-        if (ox < 0 || ox >= Ws) continue;
-        s += wy * wx * dp[oy * Ws + ox];
+        if (wx == 0.f || ox < 0 || ox >= Ws) continue;
+        for (int t = 0; t < nwy; ++t) s += wys[t] * wx * dp[oys[t] * Ws + ox];
       }
+      dx1[k * W1 + j] = s;
     }
-    dx1[k] = s;
   }
 }
 
+constexpr size_t PLANE_LDS_BYTES = 64 * 1024;   // default dynamic-LDS limit; two such workgroups share a CU
+inline unsigned row_blocks(long rows) { return (unsigned)std::max<long>(1, std::min<long>(mpa_cdiv(rows, 4), 1 << 20)); }
 inline unsigned blocks_for(long n) { return (unsigned)std::max<long>(1, std::min<long>(mpa_cdiv(n, 256), 1 << 16)); }
 
 }  // namespace
@@ -174,8 +266,13 @@ int mpa_maxpool2d_fwd(const float* x, float* y, int32_t* idx, int B, int C, int 
   const int OH = (H + 2 * ph - kh) / sh + 1, OW = (W + 2 * pw - kw) / sw + 1;
   if (OH <= 0 || OW <= 0) return MPA_ERR_ARG;
   const long planes = (long)B * C;
-  MPA_LAUNCH(maxpool_fwd_kernel, dim3(blocks_for(planes * OH * OW)), dim3(256), 0, (hipStream_t)stream, x, y, idx,
-                     planes, H, W, OH, OW, kh, kw, sh, sw, ph, pw);
+  if ((size_t)H * W * 4 <= PLANE_LDS_BYTES && planes <= 0x7fffffffL) {
+    MPA_LAUNCH(maxpool_fwd_plane_kernel, dim3((unsigned)planes), dim3(256), (size_t)H * W * 4, (hipStream_t)stream, x, y,
+               idx, H, W, OH, OW, kh, kw, sh, sw, ph, pw);
+    return mpa_launch_status();
+  }
+  MPA_LAUNCH(maxpool_fwd_kernel, dim3(row_blocks(planes * OH)), dim3(256), 0, (hipStream_t)stream, x, y, idx,
+                     planes * OH, H, W, OH, OW, kh, kw, sh, sw, ph, pw);
   return mpa_launch_status();
 }
 
@@ -184,15 +281,20 @@ int mpa_maxpool2d_bwd(const float* dy, const int32_t* idx, float* dx, int B, int
   if (!dy || !idx || !dx) return MPA_ERR_ARG;
   const int OH = (H + 2 * ph - kh) / sh + 1, OW = (W + 2 * pw - kw) / sw + 1;
   const long planes = (long)B * C;
-  MPA_LAUNCH(maxpool_bwd_kernel, dim3(blocks_for(planes * H * W)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx,
-                     planes, H, W, OH, OW, kh, kw, sh, sw, ph, pw);
+  if ((size_t)OH * OW * 8 <= PLANE_LDS_BYTES && planes <= 0x7fffffffL) {
+    MPA_LAUNCH(maxpool_bwd_plane_kernel, dim3((unsigned)planes), dim3(256), (size_t)OH * OW * 8, (hipStream_t)stream, dy,
+               idx, dx, H, W, OH, OW, kh, kw, sh, sw, ph, pw);
+    return mpa_launch_status();
+  }
+  MPA_LAUNCH(maxpool_bwd_kernel, dim3(row_blocks(planes * H)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx,
+                     planes * H, H, W, OH, OW, kh, kw, sh, sw, ph, pw);
   return mpa_launch_status();
 }
 
 int mpa_upcat_fwd(const float* x1, const float* skip, float* out, int B, int C1, int H1, int W1, int Cs, int Hs, int Ws,
                   void* stream) {
   if (!x1 || !skip || !out || Hs < 2 * H1 || Ws < 2 * W1) return MPA_ERR_ARG;
-  MPA_LAUNCH(upcat_fwd_kernel, dim3(blocks_for((long)B * (Cs + C1) * Hs * Ws)), dim3(256), 0, (hipStream_t)stream, x1,
+  MPA_LAUNCH(upcat_fwd_kernel, dim3(row_blocks((long)B * (Cs + C1) * Hs)), dim3(256), 0, (hipStream_t)stream, x1,
                      skip, out, B, C1, H1, W1, Cs, Hs, Ws);
   return mpa_launch_status();
 }
@@ -200,8 +302,8 @@ int mpa_upcat_fwd(const float* x1, const float* skip, float* out, int B, int C1,
 int mpa_upcat_bwd(const float* dout, float* dx1, float* dskip, int B, int C1, int H1, int W1, int Cs, int Hs, int Ws,
                   void* stream) {
   if (!dout || !dx1 || !dskip) return MPA_ERR_ARG;
-  const long n = (long)B * Cs * Hs * Ws + (long)B * C1 * H1 * W1;
-  MPA_LAUNCH(upcat_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, dout, dx1, dskip, B, C1, H1, W1,
+  const long n = (long)B * Cs * Hs + (long)B * C1 * H1;
+  MPA_LAUNCH(upcat_bwd_kernel, dim3(row_blocks(n)), dim3(256), 0, (hipStream_t)stream, dout, dx1, dskip, B, C1, H1, W1,
                      Cs, Hs, Ws);
   return mpa_launch_status();
 }
