@@ -30,7 +30,15 @@ struct FwdPlan {
   int NB, PB, TH, TW, tilesY, tilesX, CK, nChunks, IH, IW, LW, CHP, COT, COTP, coTiles, OH, OW, quad;
   size_t lds_bytes;
   bool ok;
+  int KWS, KWP;   // tap-vector filter layout (kw 15 / 9, PB >= 4): kernel specialised on kw, slab rows of KWP taps
 };
+
+// Which problems use the tap-vector layout [ck][cout][dx padded to KWP]: the A operand of 4 consecutive taps is then one
+// ds_read_b128 and every B read is base + immediate, i.e. ~0.6 instead of ~1.2 non-MFMA vector instructions per MFMA for
+// the 16-cout kernels (each such instruction costs the SIMD about 4 of the 32 cycles an MFMA occupies).
+// Measured: +4..8 % for NB <= 2; the 64-cout tile (NB = 4, already at 1 operand read per 2.7 MFMAs) loses 5 % to the
+// extra live registers, so it keeps the tap-major layout.
+inline int fwd_kw_special(int kw, int NB, int PB) { return ((kw == 15 || kw == 9) && PB >= 4 && NB <= 2) ? kw : 0; }
 
 inline int round_mod(int v, int m, int r) {  // smallest x >= v with x % m == r
   int x = v + ((r - v % m) % m + m) % m;
@@ -84,8 +92,11 @@ FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
             const int CHP = round_mod(IH * LW, 32, 16);
             int CK = 4;
             while (CK < 32 && CK < cin4 && kw * (CK / 4) < 15) CK *= 2;
+            const int KWS = fwd_kw_special(kw, NB, PB), KWP = (kw + 3) & ~3;
+            const int cotp = KWS ? COT : COTP;
             auto lds_words = [&](int ck) {
-              return mpa_cdiv((long)ck * CHP, 64) * 64 + 2 * (mpa_cdiv((long)kw * ck * COTP, 64) * 64);
+              const long slab = KWS ? (long)ck * COT * KWP : (long)kw * ck * COTP;
+              return mpa_cdiv((long)ck * CHP, 64) * 64 + 2 * (mpa_cdiv(slab, 64) * 64);
             };
             while (CK > 4 && lds_words(CK) * 4 > 52 * 1024) CK /= 2;   // keep three workgroups per CU when the chunk allows
             const size_t lds = (size_t)lds_words(CK) * 4;
@@ -108,8 +119,8 @@ FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
                                 1e-3 * blocks;
             if (cost < bestcost) {
               bestcost = cost;
-              best = FwdPlan{NB, PB, TH, TW, ty, tx, CK, (int)mpa_cdiv(Cin, CK), IH, IW, LW, CHP, COT, COTP, coTiles, OH, OW,
-                             quad, lds, true};
+              best = FwdPlan{NB, PB, TH, TW, ty, tx, CK, (int)mpa_cdiv(Cin, CK), IH, IW, LW, CHP, COT, cotp, coTiles, OH, OW,
+                             quad, lds, true, KWS, KWP};
             }
           }
         }
@@ -318,7 +329,7 @@ struct ConvFwdParams {
 };
 
 // ------------------------------------------------------------------------------------------------ forward kernel
-template <int NB, int PB>
+template <int NB, int PB, int KW = 0>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lds_in = lds;
@@ -353,7 +364,16 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
     for (int j = 0; j < PB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const float* xb = p.x + (long)b * p.Cin * p.H * p.W;
-  const int slab = p.kw * p.CK * p.COTP;
+  constexpr int KWP = (KW + 3) & ~3;
+  const int slab = KW ? p.CK * p.COTP * KWP : p.kw * p.CK * p.COTP;
+  // tap-vector layout: lane (kq, l16) owns the KWP-tap row of (channel kq, cout l16); with 16-tap rows the four 16-byte
+  // chunks of a row are rotated by l16>>2 (done by the packer) so that 16 lanes hit 16 disjoint bank quads
+  int arow[KWP / 4 > 0 ? KWP / 4 : 1];
+  if constexpr (KW > 0) {
+#pragma unroll
+    for (int g = 0; g < KWP / 4; ++g)
+      arow[g] = (kq * p.COTP + l16) * KWP + (KWP == 16 ? ((g + (l16 >> 2)) & 3) * 4 : g * 4);
+  }
   const float* wtile = p.wp + (long)cot * p.nChunks * p.kh * slab;
   const int astep = p.CK * p.COTP;
 
@@ -373,6 +393,36 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
       const float* lds_w = lds_w0 + (dy & 1) * p.SL64;
       if (dy + 1 < p.kh && do_stage)
         glds_copy16(lds_w0 + ((dy + 1) & 1) * p.SL64, wtile + (long)(c * p.kh + dy + 1) * slab, tid, slab / 4);
+      if constexpr (KW > 0) {
+        if (p.dbg != 2)
+        for (int j = 0; j < p.CK / 4; ++j) {
+          const float* aw = lds_w + j * 4 * p.COTP * KWP;
+          const float* bp = lds_in + j * 4 * p.CHP + dy * p.LW;
+#pragma unroll
+          for (int g = 0; g < KWP / 4; ++g) {
+            const int taps = KW - 4 * g >= 4 ? 4 : KW - 4 * g;
+            f32x4 a4[NB];
+            float bv[4][PB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) a4[nb] = *(const f32x4*)(aw + arow[g] + nb * 16 * KWP);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (u < taps) {
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) bv[u][pb] = bp[boff[pb] + 4 * g + u];
+              }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (u < taps) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                  for (int pb = 0; pb < PB; ++pb)
+                    acc[nb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[nb][u], bv[u][pb], acc[nb][pb], 0, 0, 0);
+              }
+          }
+        }
+      } else
       if (p.dbg != 2)
       for (int j = 0; j < p.CK / 4; ++j) {
         const float* ap = lds_w + j * 4 * p.COTP + aoff;
@@ -479,35 +529,43 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
   }
 }
 
-template <int NB, int PB>
-void fwd_allow_big_lds() {
-  static bool done = false;
-  if (!done) {
-    (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<NB, PB>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    done = true;
+template <int NB, int PB, int KW>
+int launch_fwd_one(const FwdPlan& pl, const ConvFwdParams& p, dim3 grid, hipStream_t s) {
+  static bool big_lds = false;
+  if (!big_lds) {
+    (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<NB, PB, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    big_lds = true;
   }
+  MPA_LAUNCH((conv_fwd_kernel<NB, PB, KW>), grid, dim3(256), pl.lds_bytes, s, p);
+  return mpa_launch_status();
+}
+
+template <int NB, int PB>
+int launch_fwd_kw(const FwdPlan& pl, const ConvFwdParams& p, dim3 grid, hipStream_t s) {
+  if constexpr (PB >= 4 && NB <= 2) {
+    if (pl.KWS == 15) return launch_fwd_one<NB, PB, 15>(pl, p, grid, s);
+    if (pl.KWS == 9) return launch_fwd_one<NB, PB, 9>(pl, p, grid, s);
+  }
+  if (pl.KWS != 0) return MPA_ERR_UNSUPPORTED;
+  return launch_fwd_one<NB, PB, 0>(pl, p, grid, s);
 }
 
 template <int NB>
 int launch_fwd_nb(const FwdPlan& pl, const ConvFwdParams& p, hipStream_t s) {
   dim3 grid((unsigned)(p.B * pl.tilesY * pl.tilesX), (unsigned)pl.coTiles);
-  fwd_allow_big_lds<NB, 1>(); fwd_allow_big_lds<NB, 2>(); fwd_allow_big_lds<NB, 4>(); fwd_allow_big_lds<NB, 6>();
-  if constexpr (NB <= 4) fwd_allow_big_lds<NB, 8>();
-  if constexpr (NB <= 2) fwd_allow_big_lds<NB, 12>();
   switch (pl.PB) {
-    case 1: MPA_LAUNCH((conv_fwd_kernel<NB, 1>), grid, dim3(256), pl.lds_bytes, s, p); break;
-    case 2: MPA_LAUNCH((conv_fwd_kernel<NB, 2>), grid, dim3(256), pl.lds_bytes, s, p); break;
-    case 4: MPA_LAUNCH((conv_fwd_kernel<NB, 4>), grid, dim3(256), pl.lds_bytes, s, p); break;
-    case 6: MPA_LAUNCH((conv_fwd_kernel<NB, 6>), grid, dim3(256), pl.lds_bytes, s, p); break;
+    case 1: return launch_fwd_kw<NB, 1>(pl, p, grid, s);
+    case 2: return launch_fwd_kw<NB, 2>(pl, p, grid, s);
+    case 4: return launch_fwd_kw<NB, 4>(pl, p, grid, s);
+    case 6: return launch_fwd_kw<NB, 6>(pl, p, grid, s);
     case 8:
-      if constexpr (NB <= 4) { MPA_LAUNCH((conv_fwd_kernel<NB, 8>), grid, dim3(256), pl.lds_bytes, s, p); break; }
+      if constexpr (NB <= 4) return launch_fwd_kw<NB, 8>(pl, p, grid, s);
       return MPA_ERR_UNSUPPORTED;
     case 12:
-      if constexpr (NB <= 2) { MPA_LAUNCH((conv_fwd_kernel<NB, 12>), grid, dim3(256), pl.lds_bytes, s, p); break; }
+      if constexpr (NB <= 2) return launch_fwd_kw<NB, 12>(pl, p, grid, s);
       return MPA_ERR_UNSUPPORTED;
     default: return MPA_ERR_UNSUPPORTED;
   }
-  return mpa_launch_status();
 }
 
 int launch_fwd(const FwdPlan& pl, const ConvFwdParams& p, hipStream_t s) {
@@ -532,21 +590,32 @@ struct PackParams {
   int mode, xphase;                // xphase: strided-W backward (dx taken from co' / Cin)
   int CinP, CoutP, kh, kw;         // dims of the conv that will consume the packed filters
   int CK, nChunks, COT, COTP, coTiles;
+  int KWP;                         // > 0: tap-vector layout packed[cot][chunk][dy][ck][COT][KWP] (see fwd_kw_special)
   long total;
 };
 
 __global__ void conv_pack_kernel(const PackParams p) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < p.total; i += (long)gridDim.x * blockDim.x) {
     long r = i;
-    const int col = (int)(r % p.COTP); r /= p.COTP;
-    const int ck = (int)(r % p.CK); r /= p.CK;
-    const int dx = (int)(r % p.kw); r /= p.kw;
+    int col, ck, dx;
+    if (p.KWP > 0) {
+      int pos = (int)(r % p.KWP); r /= p.KWP;
+      col = (int)(r % p.COTP); r /= p.COTP;
+      ck = (int)(r % p.CK); r /= p.CK;
+      // 16-tap rows: chunk g of the row sits at position (g + (col&15)>>2) & 3 -- undo the rotation to find the tap
+      if (p.KWP == 16) pos = ((((pos >> 2) - ((col & 15) >> 2)) & 3) << 2) | (pos & 3);
+      dx = pos;
+    } else {
+      col = (int)(r % p.COTP); r /= p.COTP;
+      ck = (int)(r % p.CK); r /= p.CK;
+      dx = (int)(r % p.kw); r /= p.kw;
+    }
     const int dy = (int)(r % p.kh); r /= p.kh;
     const int chunk = (int)(r % p.nChunks); r /= p.nChunks;
     const int cot = (int)r;
     const int co = cot * p.COT + col, ci = chunk * p.CK + ck;
     float v = 0.f;
-    if (col < p.COT && co < p.CoutP && ci < p.CinP) {
+    if (col < p.COT && co < p.CoutP && ci < p.CinP && dx < p.kw) {
       if (p.mode == 0) {
         v = p.w[(((long)co * p.Cin_w + ci) * p.kh_w + dy) * p.kw_w + dx];
       } else if (!p.xphase) {
@@ -980,7 +1049,7 @@ int64_t mpa_conv2d_packed_floats(const mpa_conv_desc* d, int mode) {
   }
   if (!pl.ok) return MPA_ERR_UNSUPPORTED;
   const int kh = d->kh, kw = (mode == 1 && bwd_data_geom(d).xphase) ? 1 : d->kw;
-  return (int64_t)pl.coTiles * pl.nChunks * kh * kw * pl.CK * pl.COTP;
+  return (int64_t)pl.coTiles * pl.nChunks * kh * (pl.KWS ? pl.KWP : kw) * pl.CK * pl.COTP;
 }
 
 int mpa_conv2d_pack(const mpa_conv_desc* d, int mode, const float* w, float* w_packed, void* stream) {
@@ -1001,7 +1070,8 @@ int mpa_conv2d_pack(const mpa_conv_desc* d, int mode, const float* w, float* w_p
   }
   if (!pl.ok) return MPA_ERR_UNSUPPORTED;
   p.CK = pl.CK; p.nChunks = pl.nChunks; p.COT = pl.COT; p.COTP = pl.COTP; p.coTiles = pl.coTiles;
-  p.total = (long)pl.coTiles * pl.nChunks * p.kh * p.kw * pl.CK * pl.COTP;
+  p.KWP = pl.KWS ? pl.KWP : 0;
+  p.total = (long)pl.coTiles * pl.nChunks * p.kh * (pl.KWS ? pl.KWP : p.kw) * pl.CK * pl.COTP;
   const int blocks = (int)std::min<long>(mpa_cdiv(p.total, 256), 4096);
   MPA_LAUNCH(conv_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
   return mpa_launch_status();
@@ -1019,7 +1089,7 @@ static int conv_fwd_impl(int B, int Cin, int H, int W, int Cout, int kh, int kw,
   p.TH = pl.TH; p.TW = pl.TW; p.tilesY = pl.tilesY; p.tilesX = pl.tilesX; p.CK = pl.CK; p.nChunks = pl.nChunks;
   p.IH = pl.IH; p.IW = pl.IW; p.LW = pl.LW; p.CHP = pl.CHP; p.COT = pl.COT; p.COTP = pl.COTP;
   p.IN64 = (int)(mpa_cdiv((long)pl.CK * pl.CHP, 64) * 64);
-  p.SL64 = (int)(mpa_cdiv((long)kw * pl.CK * pl.COTP, 64) * 64);
+  p.SL64 = (int)(mpa_cdiv((long)(pl.KWS ? pl.KWP : kw) * pl.CK * pl.COTP, 64) * 64);
   p.quad = pl.quad;
   { const char* e = getenv("MPA_DEBUG_FWD"); p.dbg = e ? atoi(e) : 0; }
   p.act = act; p.slope = slope;
@@ -1074,8 +1144,8 @@ int mpa_conv2d_describe_plan(const mpa_conv_desc* d, int mode, char* buf, int bu
     f = plan_fwd(d->B, g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw);
   }
   if (!f.ok) return MPA_ERR_UNSUPPORTED;
-  snprintf(buf, buflen, "fwd<%d,%d> COT=%d coTiles=%d CK=%d chunks=%d tile=%dx%d tiles=%dx%d halo=%dx%d LW=%d quad=%d lds=%zuB",
-           f.NB, f.PB, f.COT, f.coTiles, f.CK, f.nChunks, f.TH, f.TW, f.tilesY, f.tilesX, f.IH, f.IW, f.LW, f.quad, f.lds_bytes);
+  snprintf(buf, buflen, "fwd<%d,%d> COT=%d coTiles=%d CK=%d chunks=%d tile=%dx%d tiles=%dx%d halo=%dx%d LW=%d quad=%d kwvec=%d lds=%zuB",
+           f.NB, f.PB, f.COT, f.coTiles, f.CK, f.nChunks, f.TH, f.TW, f.tilesY, f.tilesX, f.IH, f.IW, f.LW, f.quad, f.KWS, f.lds_bytes);
   return MPA_OK;
 }
 
