@@ -394,10 +394,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
       if (dy + 1 < p.kh && do_stage)
         glds_copy16(lds_w0 + ((dy + 1) & 1) * p.SL64, wtile + (long)(c * p.kh + dy + 1) * slab, tid, slab / 4);
       if constexpr (KW > 0) {
+        // kw = 15 always runs with 4-channel chunks (plan_fwd), so the channel-group loop has a single trip there
+        const int nj = KW == 15 ? 1 : p.CK / 4;
         if (p.dbg != 2)
-        for (int j = 0; j < p.CK / 4; ++j) {
-          const float* aw = lds_w + j * 4 * p.COTP * KWP;
-          const float* bp = lds_in + j * 4 * p.CHP + dy * p.LW;
+        for (int j = 0; j < nj; ++j) {
+          const float* aw = lds_w + (KW == 15 ? 0 : j * 4 * p.COTP * KWP);
+          const float* bp = lds_in + (KW == 15 ? 0 : j * 4 * p.CHP) + dy * p.LW;
 #pragma unroll
           for (int g = 0; g < KWP / 4; ++g) {
             const int taps = KW - 4 * g >= 4 ? 4 : KW - 4 * g;

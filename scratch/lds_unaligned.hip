@@ -14,21 +14,32 @@ __global__ __launch_bounds__(256) void k(float* out, int shift, int iters) {
   float acc = 0.f;
   unsigned addr = (unsigned)((lane + shift) * 4 + (threadIdx.x >> 6) * 4096);   // byte address: lane-consecutive floats
   for (int it = 0; it < iters; ++it) {
-    if (MODE == 0) {          // 4 x b32 via 2 x read2
-      float a, b, c, d;
-      asm volatile("ds_read2_b32 %0, %2 offset1:1\n ds_read2_b32 %1, %2 offset0:2 offset1:3\n s_waitcnt lgkmcnt(0)"
-                   : "=v"(*(f32x2*)&a), "=v"(*(f32x2*)&c) : "v"(addr) : "memory");
-      acc += a;
-    } else if (MODE == 1) {   // b128
-      f32x4 v;
-      asm volatile("ds_read_b128 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
-      acc += v[0] + v[1] + v[2] + v[3];
-    } else {                  // b64 x2
-      f32x2 v, w;
-      asm volatile("ds_read_b64 %0, %2\n ds_read_b64 %1, %2 offset:8\n s_waitcnt lgkmcnt(0)" : "=v"(v), "=v"(w) : "v"(addr) : "memory");
-      acc += v[0] + v[1] + w[0] + w[1];
+    // 4 independent requests of 4 floats each in flight, one wait
+    if (MODE == 0) {
+      f32x2 r[8];
+      asm volatile("ds_read2_b32 %0, %8 offset1:1\n ds_read2_b32 %1, %8 offset0:2 offset1:3\n"
+                   "ds_read2_b32 %2, %8 offset0:16 offset1:17\n ds_read2_b32 %3, %8 offset0:18 offset1:19\n"
+                   "ds_read2_b32 %4, %8 offset0:32 offset1:33\n ds_read2_b32 %5, %8 offset0:34 offset1:35\n"
+                   "ds_read2_b32 %6, %8 offset0:48 offset1:49\n ds_read2_b32 %7, %8 offset0:50 offset1:51\n s_waitcnt lgkmcnt(0)"
+                   : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+                   : "v"(addr) : "memory");
+      acc += r[0][0] + r[0][1] + r[1][0] + r[1][1] + r[2][0] + r[4][0] + r[6][0];
+    } else if (MODE == 1) {
+      f32x4 v[4];
+      asm volatile("ds_read_b128 %0, %4\n ds_read_b128 %1, %4 offset:64\n ds_read_b128 %2, %4 offset:128\n"
+                   "ds_read_b128 %3, %4 offset:192\n s_waitcnt lgkmcnt(0)"
+                   : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(addr) : "memory");
+      acc += v[0][0] + v[0][1] + v[0][2] + v[0][3] + v[1][0] + v[2][0] + v[3][0];
+    } else {
+      f32x2 v[8];
+      asm volatile("ds_read_b64 %0, %8\n ds_read_b64 %1, %8 offset:8\n ds_read_b64 %2, %8 offset:64\n ds_read_b64 %3, %8 offset:72\n"
+                   "ds_read_b64 %4, %8 offset:128\n ds_read_b64 %5, %8 offset:136\n ds_read_b64 %6, %8 offset:192\n"
+                   "ds_read_b64 %7, %8 offset:200\n s_waitcnt lgkmcnt(0)"
+                   : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                   : "v"(addr) : "memory");
+      acc += v[0][0] + v[0][1] + v[1][0] + v[1][1] + v[2][0] + v[4][0] + v[6][0];
     }
-    addr ^= 64;
+    addr ^= 1024;
   }
   out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
@@ -49,7 +60,7 @@ void run(const char* name, int shift) {
   int bad = 0;
   for (int t = 0; t < 256; ++t) {
     int base = (t & 63) + shift + (t >> 6) * 1024;
-    float want = MODE == 0 ? (float)base : (float)(4 * base + 6);
+    float want = (float)(4 * base + 6 + 3 * base + 16 + 32 + 48);
     if (h[t] != want) ++bad;
   }
   printf("%s shift=%d: %.3f ms, %d/256 wrong, hipError=%s\n", name, shift, ms, bad, hipGetErrorString(hipGetLastError()));
