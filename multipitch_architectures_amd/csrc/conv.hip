@@ -31,6 +31,7 @@ struct FwdPlan {
   size_t lds_bytes;
   bool ok;
   int KWS, KWP;   // tap-vector filter layout (kw 15 / 9, PB >= 4): kernel specialised on kw, slab rows of KWP taps
+  int KS;         // input-channel split: blockIdx.z owns nChunks/KS chunks and adds its partial sums atomically
 };
 
 // Which problems use the tap-vector layout [ck][cout][dx padded to KWP]: the A operand of 4 consecutive taps is then one
@@ -45,7 +46,9 @@ inline int round_mod(int v, int m, int r) {  // smallest x >= v with x % m == r
   return x;
 }
 
-FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw) {
+// allow_split: the launch may add channel slices atomically (backward-data only: the forward pass stays bit-reproducible)
+FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                 bool allow_split = false) {
   FwdPlan best{};
   best.ok = false;
   const int OH = (H + 2 * ph - kh) / sh + 1, OW = (W + 2 * pw - kw) / sw + 1;
@@ -107,20 +110,41 @@ FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
             const long blocks = (long)B * ty * tx * coTiles;
             const long rounds = mpa_cdiv(blocks, 256 * bpc);
             // cycles one workgroup needs when it shares each SIMD with bpc-1 others
-            const double per_block = (double)P * NB * (1.0 + 0.05 * IH * IW / P + 0.15 * (NB + PB) / (double)(NB * PB)) *
-                                     (1.0 + 0.02 * lwi + 0.3 / (kw * (CK / 4))) * (quad ? 1.0 : 1.08);
+            // operand term: every non-MFMA vector instruction costs ~4 of an MFMA's 32 cycles -- (NB+PB) LDS reads plus
+            // their address arithmetic per NB*PB MFMAs (about half of that in the tap-vector kernels); barrier term:
+            // ~400 cycles per (chunk, filter row) against kw*(CK/4)*NB*PB MFMAs of 32 cycles
+            const double opnd = (KWS ? 0.13 : 0.25) * (NB + PB) / (double)(NB * PB);
+            const double per_block = (double)P * NB * (1.0 + 0.05 * IH * IW / P + opnd) * (1.0 + 0.02 * lwi) *
+                                     (1.0 + 12.5 / ((double)kw * (CK / 4) * NB * PB)) * (quad ? 1.0 : 1.08);
             // large grids: throughput (blocks * per_block / 256 CUs); small grids: whole rounds
             const double fill = (double)(TH * TW) / P;      // lanes doing useful work
             // few rounds: whole rounds are paid (measured: 3.01 rounds cost as much as 3.32); many rounds: workgroups
             // drift apart and only ~a third of a round is lost at the end
             const double frac_rounds = (double)blocks / (256.0 * bpc);
             const double eff_rounds = rounds <= 3 ? (double)rounds : frac_rounds + 0.35;
-            const double cost = eff_rounds * bpc * per_block * (1.0 + 0.25 * (1.0 - fill)) +
+            const long occ = std::min<long>(bpc, mpa_cdiv(blocks, 256));     // workgroups actually sharing a CU
+            double cost = eff_rounds * occ * per_block * (1.0 + 0.25 * (1.0 - fill)) +
                                 1e-3 * blocks;
+            // Small grids (small batch x small image: the U-Net's deep levels): split the input channels over
+            // blockIdx.z so that efficient wave tiles still fill the chip; partial sums are added atomically into a
+            // zeroed output.  Each extra slice pays a prologue/epilogue (~6 % of a full-K workgroup).
+            const int nChunks = (int)mpa_cdiv(Cin, CK);
+            int KS = 1;
+            static const int ks_max = getenv("MPA_FWD_KS_MAX") ? atoi(getenv("MPA_FWD_KS_MAX")) : 16;   // diagnostics
+            if (rounds <= 2 && allow_split) {
+              for (int ks = 2; ks <= ks_max && ks <= nChunks; ks *= 2) {
+                const long r2 = mpa_cdiv(blocks * ks, 256 * bpc);
+                const double f2 = (double)(blocks * ks) / (256.0 * bpc);
+                const double e2 = r2 <= 3 ? (double)r2 : f2 + 0.35;
+                const long occ2 = std::min<long>(bpc, mpa_cdiv(blocks * ks, 256));
+                const double c2 = e2 * occ2 * per_block * (1.0 / ks + 0.06) * (1.0 + 0.25 * (1.0 - fill)) + 1e-3 * blocks * ks;
+                if (c2 < cost) { cost = c2; KS = ks; }
+              }
+            }
             if (cost < bestcost) {
               bestcost = cost;
-              best = FwdPlan{NB, PB, TH, TW, ty, tx, CK, (int)mpa_cdiv(Cin, CK), IH, IW, LW, CHP, COT, cotp, coTiles, OH, OW,
-                             quad, lds, true, KWS, KWP};
+              best = FwdPlan{NB, PB, TH, TW, ty, tx, CK, nChunks, IH, IW, LW, CHP, COT, cotp, coTiles, OH, OW,
+                             quad, lds, true, KWS, KWP, KS};
             }
           }
         }
@@ -326,6 +350,7 @@ struct ConvFwdParams {
   float slope;
   long outBS, outCS;   // output batch / channel strides (floats)
   int outRS, outXmul, outCdiv;
+  int chunksPer;       // input-channel chunks per blockIdx.z slice (== nChunks when the channels are not split)
 };
 
 // ------------------------------------------------------------------------------------------------ forward kernel
@@ -377,9 +402,11 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
   const float* wtile = p.wp + (long)cot * p.nChunks * p.kh * slab;
   const int astep = p.CK * p.COTP;
 
-  for (int c = 0; c < p.nChunks; ++c) {
+  const bool split = gridDim.z > 1;
+  const int c_begin = blockIdx.z * p.chunksPer, c_end = min(p.nChunks, c_begin + p.chunksPer);
+  for (int c = c_begin; c < c_end; ++c) {
     __syncthreads();   // every wave is done with the previous chunk's tile and slabs
-    const bool do_stage = (p.dbg != 1 && p.dbg != 3) || c == 0;
+    const bool do_stage = (p.dbg != 1 && p.dbg != 3) || c == c_begin;
     if (do_stage) {
       if (p.quad)
         glds_stage_x16(lds_in, xb, lane, wave, p.CK, p.IH, p.LW, p.CHP, p.IN64, c * p.CK, iy0, x0a, p.Cin, p.H, p.W);
@@ -473,7 +500,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
   // Wide path (NB*PB > 16, plain NCHW target, TW % 4 == 0, OW % 4 == 0): every 16x16 accumulator tile is transposed
   // through a wave-private LDS patch so that a lane owns 4 consecutive pixels of one cout and writes one 16-byte store
   // -- 4x fewer store instructions (measured: the 128 dword stores per lane of <4,8> cost 6.4 % of the workgroup's life).
-  if (NB * PB > 16 && p.outCdiv >= p.Cout && (p.TW & 3) == 0 && (p.OW & 3) == 0 && p.act != MPA_ACT_SIGMOID) {
+  if (!split && NB * PB > 16 && p.outCdiv >= p.Cout && (p.TW & 3) == 0 && (p.OW & 3) == 0 && p.act != MPA_ACT_SIGMOID) {
     __syncthreads();                                  // the main loop's LDS images are dead now
     float* patch = lds + wave * (16 * 20);            // [cout 16][pixel 16 (+4 pad)]
     const int co_l = lane >> 2, quad = lane & 3;      // after the transpose: lane -> (cout row, 4-pixel group)
@@ -518,14 +545,16 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
         const int co = cot * p.COT + nb * 16 + kq * 4 + r;
         if (co >= p.Cout) continue;
         float v = acc[nb][pb][r];
-        if (p.bias) v += p.bias[co];
-        v = mpa_apply_act(v, p.act, p.slope);
+        if (p.bias && blockIdx.z == 0) v += p.bias[co];
+        float* dst;
         if (p.outCdiv >= p.Cout) {            // plain NCHW store (uniform branch)
-          p.y[(long)b * p.outBS + (long)co * p.outCS + (long)oy * p.outRS + ox] = v;
+          dst = p.y + (long)b * p.outBS + (long)co * p.outCS + (long)oy * p.outRS + ox;
         } else {                              // stride-(1,kw) backward-data: cout' = (dx phase, cin)
           const int q = co / p.outCdiv, cc = co - q * p.outCdiv;
-          p.y[(long)b * p.outBS + (long)cc * p.outCS + (long)oy * p.outRS + (long)ox * p.outXmul + q] = v;
+          dst = p.y + (long)b * p.outBS + (long)cc * p.outCS + (long)oy * p.outRS + (long)ox * p.outXmul + q;
         }
+        if (split) atomicAdd(dst, v);         // channel slices accumulate into the zeroed output; activation follows
+        else *dst = mpa_apply_act(v, p.act, p.slope);
       }
     }
   }
@@ -554,7 +583,7 @@ int launch_fwd_kw(const FwdPlan& pl, const ConvFwdParams& p, dim3 grid, hipStrea
 
 template <int NB>
 int launch_fwd_nb(const FwdPlan& pl, const ConvFwdParams& p, hipStream_t s) {
-  dim3 grid((unsigned)(p.B * pl.tilesY * pl.tilesX), (unsigned)pl.coTiles);
+  dim3 grid((unsigned)(p.B * pl.tilesY * pl.tilesX), (unsigned)pl.coTiles, (unsigned)mpa_cdiv(pl.nChunks, p.chunksPer));
   switch (pl.PB) {
     case 1: return launch_fwd_kw<NB, 1>(pl, p, grid, s);
     case 2: return launch_fwd_kw<NB, 2>(pl, p, grid, s);
@@ -1047,7 +1076,7 @@ int64_t mpa_conv2d_packed_floats(const mpa_conv_desc* d, int mode) {
   } else {
     BwdDataGeom g = bwd_data_geom(d);
     if (!g.ok) return MPA_ERR_UNSUPPORTED;
-    pl = plan_fwd(d->B, g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw);
+    pl = plan_fwd(d->B, g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw, true);
   }
   if (!pl.ok) return MPA_ERR_UNSUPPORTED;
   const int kh = d->kh, kw = (mode == 1 && bwd_data_geom(d).xphase) ? 1 : d->kw;
@@ -1067,7 +1096,7 @@ int mpa_conv2d_pack(const mpa_conv_desc* d, int mode, const float* w, float* w_p
   } else {
     BwdDataGeom g = bwd_data_geom(d);
     if (!g.ok) return MPA_ERR_UNSUPPORTED;
-    pl = plan_fwd(d->B, g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw);
+    pl = plan_fwd(d->B, g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw, true);
     p.CinP = g.Cin; p.CoutP = g.Cout; p.kh = g.kh; p.kw = g.kw; p.xphase = g.xphase ? 1 : 0;
   }
   if (!pl.ok) return MPA_ERR_UNSUPPORTED;
@@ -1081,8 +1110,8 @@ int mpa_conv2d_pack(const mpa_conv_desc* d, int mode, const float* w, float* w_p
 
 static int conv_fwd_impl(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
                          const float* x, const float* wp, const float* bias, float* y, int act, float slope,
-                         long outBS, long outCS, int outRS, int outXmul, int outCdiv, hipStream_t s) {
-  FwdPlan pl = plan_fwd(B, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw);
+                         long outBS, long outCS, int outRS, int outXmul, int outCdiv, hipStream_t s, bool allow_split = false) {
+  FwdPlan pl = plan_fwd(B, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, allow_split);
   if (!pl.ok) return MPA_ERR_UNSUPPORTED;
   ConvFwdParams p{};
   p.x = x; p.wp = wp; p.bias = bias; p.y = y;
@@ -1096,7 +1125,15 @@ static int conv_fwd_impl(int B, int Cin, int H, int W, int Cout, int kh, int kw,
   { const char* e = getenv("MPA_DEBUG_FWD"); p.dbg = e ? atoi(e) : 0; }
   p.act = act; p.slope = slope;
   p.outBS = outBS; p.outCS = outCS; p.outRS = outRS; p.outXmul = outXmul; p.outCdiv = outCdiv;
-  return launch_fwd(pl, p, s);
+  p.chunksPer = (int)mpa_cdiv(pl.nChunks, pl.KS);
+  if (mpa_cdiv(pl.nChunks, p.chunksPer) <= 1) return launch_fwd(pl, p, s);
+  // channel-split launch: slices add into a zeroed output, the activation (if any) runs afterwards in place
+  (void)hipGetLastError();
+  if (hipMemsetAsync(y, 0, sizeof(float) * (size_t)B * (size_t)outBS, s) != hipSuccess) return MPA_ERR_LAUNCH;
+  p.act = MPA_ACT_NONE;
+  const int rc = launch_fwd(pl, p, s);
+  if (rc != MPA_OK || act == MPA_ACT_NONE) return rc;
+  return mpa_act_fwd(y, y, (int64_t)B * outBS, act, slope, s);
 }
 
 int mpa_conv2d_fwd(const mpa_conv_desc* d, const float* x, const float* w_packed, const float* bias, float* y,
@@ -1116,10 +1153,10 @@ int mpa_conv2d_bwd_data(const mpa_conv_desc* d, const float* dy, const float* w_
   if (!g.xphase) {
     // output of the derived conv has size H x W again
     return conv_fwd_impl(d->B, g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw, dy, w_packed, nullptr, dx,
-                         MPA_ACT_NONE, 0.f, inBS, inCS, d->W, 1, g.Cout, (hipStream_t)stream);
+                         MPA_ACT_NONE, 0.f, inBS, inCS, d->W, 1, g.Cout, (hipStream_t)stream, true);
   }
   return conv_fwd_impl(d->B, g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw, dy, w_packed, nullptr, dx,
-                       MPA_ACT_NONE, 0.f, inBS, inCS, d->W, d->sw, d->Cin, (hipStream_t)stream);
+                       MPA_ACT_NONE, 0.f, inBS, inCS, d->W, d->sw, d->Cin, (hipStream_t)stream, true);
 }
 
 int mpa_conv2d_describe_plan(const mpa_conv_desc* d, int mode, char* buf, int buflen) {
@@ -1143,11 +1180,11 @@ int mpa_conv2d_describe_plan(const mpa_conv_desc* d, int mode, char* buf, int bu
   else {
     BwdDataGeom g = bwd_data_geom(d);
     if (!g.ok) return MPA_ERR_UNSUPPORTED;
-    f = plan_fwd(d->B, g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw);
+    f = plan_fwd(d->B, g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw, true);
   }
   if (!f.ok) return MPA_ERR_UNSUPPORTED;
-  snprintf(buf, buflen, "fwd<%d,%d> COT=%d coTiles=%d CK=%d chunks=%d tile=%dx%d tiles=%dx%d halo=%dx%d LW=%d quad=%d kwvec=%d lds=%zuB",
-           f.NB, f.PB, f.COT, f.coTiles, f.CK, f.nChunks, f.TH, f.TW, f.tilesY, f.tilesX, f.IH, f.IW, f.LW, f.quad, f.KWS, f.lds_bytes);
+  snprintf(buf, buflen, "fwd<%d,%d> COT=%d coTiles=%d CK=%d chunks=%d tile=%dx%d tiles=%dx%d halo=%dx%d LW=%d quad=%d kwvec=%d ksplit=%d lds=%zuB",
+           f.NB, f.PB, f.COT, f.coTiles, f.CK, f.nChunks, f.TH, f.TW, f.tilesY, f.tilesX, f.IH, f.IW, f.LW, f.quad, f.KWS, f.KS, f.lds_bytes);
   return MPA_OK;
 }
 
