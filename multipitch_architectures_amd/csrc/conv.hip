@@ -351,6 +351,7 @@ struct ConvFwdParams {
   long outBS, outCS;   // output batch / channel strides (floats)
   int outRS, outXmul, outCdiv;
   int chunksPer;       // input-channel chunks per blockIdx.z slice (== nChunks when the channels are not split)
+  int coTiles, nTilesAll;   // cout tiles; pixel tiles over the whole batch
 };
 
 // ------------------------------------------------------------------------------------------------ forward kernel
@@ -360,12 +361,18 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
   float* lds_in = lds;
   float* lds_w0 = lds + p.IN64;          // two filter-slab buffers: slab dy+1 streams in while dy is consumed
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int bid = blockIdx.x;
+  // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so workgroup w runs
+  // on XCD w%8 as the (w/8)-th of that XCD.  The coTiles workgroups that read the same input tile are made consecutive
+  // *within one XCD*: the tile is fetched from HBM once and hit in that L2 by the others.
+  const int w = blockIdx.x;
+  const int seq = w >> 3;
+  const int cot = seq % p.coTiles;
+  int bid = (seq / p.coTiles) * 8 + (w & 7);
+  if (bid >= p.nTilesAll) return;          // padding of the last group of 8 pixel tiles (whole workgroup)
   const int tx = bid % p.tilesX;
   bid /= p.tilesX;
   const int ty = bid % p.tilesY;
   const int b = bid / p.tilesY;
-  const int cot = blockIdx.y;
   const int oy0 = ty * p.TH, ox0 = tx * p.TW;
   const int iy0 = oy0 * p.sh - p.ph, ix0 = ox0 * p.sw - p.pw;
   const int npix = p.TH * p.TW;
@@ -583,7 +590,7 @@ int launch_fwd_kw(const FwdPlan& pl, const ConvFwdParams& p, dim3 grid, hipStrea
 
 template <int NB>
 int launch_fwd_nb(const FwdPlan& pl, const ConvFwdParams& p, hipStream_t s) {
-  dim3 grid((unsigned)(p.B * pl.tilesY * pl.tilesX), (unsigned)pl.coTiles, (unsigned)mpa_cdiv(pl.nChunks, p.chunksPer));
+  dim3 grid((unsigned)(mpa_cdiv(p.nTilesAll, 8) * 8 * pl.coTiles), 1, (unsigned)mpa_cdiv(pl.nChunks, p.chunksPer));
   switch (pl.PB) {
     case 1: return launch_fwd_kw<NB, 1>(pl, p, grid, s);
     case 2: return launch_fwd_kw<NB, 2>(pl, p, grid, s);
@@ -1126,6 +1133,7 @@ static int conv_fwd_impl(int B, int Cin, int H, int W, int Cout, int kh, int kw,
   p.act = act; p.slope = slope;
   p.outBS = outBS; p.outCS = outCS; p.outRS = outRS; p.outXmul = outXmul; p.outCdiv = outCdiv;
   p.chunksPer = (int)mpa_cdiv(pl.nChunks, pl.KS);
+  p.coTiles = pl.coTiles; p.nTilesAll = B * pl.tilesY * pl.tilesX;
   if (mpa_cdiv(pl.nChunks, p.chunksPer) <= 1) return launch_fwd(pl, p, s);
   // channel-split launch: slices add into a zeroed output, the activation (if any) runs afterwards in place
   (void)hipGetLastError();
