@@ -694,6 +694,7 @@ struct WgPlan {
   int NBC, NTW, COT, coTiles, nPerBlock, nTiles, Ntot, XCH, TH, TW, DP, tilesY, tilesX, IH, IW, LW, XCHP, DCP, S, OH, OW;
   size_t lds_bytes;
   bool ok;
+  int quad, xshift;   // 16-byte LDS-DMA staging: 4-aligned window origin (x0a = ix0 - xshift), pitches % 4 == 0
 };
 
 WgPlan plan_wgrad(const mpa_conv_desc* d) {
@@ -716,27 +717,37 @@ WgPlan plan_wgrad(const mpa_conv_desc* d) {
     pl.nTiles = (int)mpa_cdiv(Ntot, pl.nPerBlock);
     pl.XCH = std::min(d->Cin, (pl.nPerBlock + khkw - 2) / khkw + 1);
     const double pad_eff = ((double)pl.coTiles * pl.COT / d->Cout) * ((double)pl.nTiles * pl.nPerBlock / Ntot);
+    static const int force_txn = getenv("MPA_WG_TXN") ? atoi(getenv("MPA_WG_TXN")) : 0;   // diagnostics
     for (int txn = 1; txn <= std::min(OW, 64); ++txn) {
+      if (force_txn && txn != std::min(force_txn, OW)) continue;
       const int TW = (int)mpa_cdiv(OW, txn);
       const int DP = (int)mpa_cdiv(TW, 4) * 4;
       const int IW = (DP - 1) * d->sw + d->kw;
-      const int LW = IW | 1;
+      // 16-byte LDS-DMA staging needs stride 1, W and OW multiples of 4 and tile origins on multiples of 4
+      const int quad = (d->sw == 1 && d->W % 4 == 0 && OW % 4 == 0 && (TW % 4 == 0 || txn == 1)) ? 1 : 0;
+      const int xshift = quad ? ((-d->pw) % 4 + 4) % 4 : 0;
+      const int LW = quad ? (int)mpa_cdiv(IW + 3, 4) * 4 : (IW | 1);
       for (int TH = std::min(OH, 64); TH >= 1; --TH) {
         const int IH = (TH - 1) * d->sh + d->kh;
         const int XCHP = IH * LW;
-        const int DCP = round_mod(TH * DP, 32, 2);
+        const int DCP = round_mod(TH * DP, 32, quad ? 4 : 2);
         const long floats = mpa_cdiv((long)pl.XCH * XCHP, 64) * 64 + mpa_cdiv((long)pl.COT * DCP, 64) * 64;
         if (floats * 4 > 64 * 1024) continue;
         const int ty = (int)mpa_cdiv(OH, TH);
-        // cycles per tile: MFMA issue (per wave) + un-overlapped share of the staging (~100 cycles per float per thread)
-        const double mfma = (double)TH * (DP / 4) * pl.NBC * pl.NTW * 32.0;
-        const double stage = (double)(pl.XCH * IH * IW + pl.COT * TH * DP) / 256.0 * 100.0;
-        const double cost = (double)ty * txn * (mfma + 0.6 * stage + 600.0) * pad_eff;
+        // cycles per tile: MFMA issue (per wave) + staging.  An LDS-DMA wave instruction costs the CU ~80 cycles
+        // whatever its width: 64 words (dword form) or 256 words (16-byte form) each, four waves issuing in turn.
+        // per k-step: NBC*NTW MFMAs of 32 cycles plus ~2 non-MFMA vector instructions (read + address) per operand at
+        // ~4 cycles each; per tile row: ~30 instructions of loop set-up (measured: 37x4 tiles ran 26 % slower than 8x36)
+        const double mfma = (double)TH * ((DP / 4) * (pl.NBC * pl.NTW * 32.0 + 8.0 * (pl.NBC + pl.NTW)) + 120.0);
+        const double words = (double)pl.XCH * IH * LW + (double)pl.COT * TH * DP;
+        const double stage = words / (quad ? 256.0 : 64.0) * 80.0;
+        const double cost = (double)ty * txn * (mfma + 0.7 * stage + 600.0) * pad_eff;
         if (cost < bestcost) {
           bestcost = cost;
           best = pl;
           best.TH = TH; best.TW = TW; best.DP = DP; best.tilesY = ty; best.tilesX = txn; best.IH = IH; best.IW = IW;
           best.LW = LW; best.XCHP = XCHP; best.DCP = DCP; best.lds_bytes = (size_t)floats * 4; best.ok = true;
+          best.quad = quad; best.xshift = xshift;
         }
         break;   // largest TH that fits for this TW
       }
@@ -764,6 +775,7 @@ struct WgParams {
   int COT, nPerBlock, Ntot, XCH, TH, TW, DP, tilesY, tilesX, IH, IW, LW, XCHP, DCP, S;
   int TX64, TD64;   // LDS words of the X / dY images, each rounded up to a multiple of 64
   int with_bias;   // workspace rows carry one extra column: sum over pixels of dY (the bias gradient)
+  int quad, xshift;
 };
 
 template <int NBC, int NTW>
@@ -785,7 +797,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgParams p) {
     if (n >= p.Ntot) n = nblk0;
     const int ci = n / khkw, r = n - ci * khkw;
     const int dy = r / p.kw, dx = r - dy * p.kw;
-    xoff[t] = (ci - ci_first) * p.XCHP + dy * p.LW + dx + kq * p.sw;
+    xoff[t] = (ci - ci_first) * p.XCHP + dy * p.LW + dx + kq * p.sw + p.xshift;
   }
   const int aoff = l16 * p.DCP + kq;
   const int NtotP = p.Ntot + (p.with_bias ? 1 : 0);
@@ -806,11 +818,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgParams p) {
     const int oy0 = ty * p.TH, ox0 = tx * p.TW;
     const int iy0 = oy0 * p.sh - p.ph, ix0 = ox0 * p.sw - p.pw;
     __syncthreads();
-    glds_stage_x(lds_x, p.x + (long)b * p.Cin * p.H * p.W, lane, wave, p.XCH, p.IH, p.IW, p.LW, p.XCHP, p.TX64, ci_first,
-                 iy0, ix0, p.Cin, p.H, p.W);
     // dY tile: columns >= TW belong to the neighbouring tile -> clip the readable width at ox0+TW
-    glds_stage_dy(lds_dy, p.dy + (long)b * p.Cout * p.OH * p.OW, lane, wave, p.COT, p.TH, p.DP, p.DCP, p.TD64, cot * p.COT,
-                  oy0, ox0, p.Cout, p.OH, p.OW, min(p.OW, ox0 + p.TW));
+    if (p.quad) {
+      glds_stage_x16(lds_x, p.x + (long)b * p.Cin * p.H * p.W, lane, wave, p.XCH, p.IH, p.LW, p.XCHP, p.TX64, ci_first,
+                     iy0, ix0 - p.xshift, p.Cin, p.H, p.W);
+      glds_stage_dy16(lds_dy, p.dy + (long)b * p.Cout * p.OH * p.OW, lane, wave, p.COT, p.TH, p.DP, p.DCP, p.TD64,
+                      cot * p.COT, oy0, ox0, p.Cout, p.OH, p.OW, min(p.OW, ox0 + p.TW));
+    } else {
+      glds_stage_x(lds_x, p.x + (long)b * p.Cin * p.H * p.W, lane, wave, p.XCH, p.IH, p.IW, p.LW, p.XCHP, p.TX64, ci_first,
+                   iy0, ix0, p.Cin, p.H, p.W);
+      glds_stage_dy(lds_dy, p.dy + (long)b * p.Cout * p.OH * p.OW, lane, wave, p.COT, p.TH, p.DP, p.DCP, p.TD64, cot * p.COT,
+                    oy0, ox0, p.Cout, p.OH, p.OW, min(p.OW, ox0 + p.TW));
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (do_bias) {
@@ -1178,9 +1197,9 @@ int mpa_conv2d_describe_plan(const mpa_conv_desc* d, int mode, char* buf, int bu
     }
     WgPlan w = plan_wgrad(d);
     if (!w.ok) return MPA_ERR_UNSUPPORTED;
-    snprintf(buf, buflen, "wgrad<%d,%d> COT=%d coTiles=%d nPerBlock=%d nTiles=%d XCH=%d tile=%dx%d (DP %d) tiles=%dx%d S=%d lds=%zuB",
+    snprintf(buf, buflen, "wgrad<%d,%d> COT=%d coTiles=%d nPerBlock=%d nTiles=%d XCH=%d tile=%dx%d (DP %d) tiles=%dx%d S=%d quad=%d lds=%zuB",
              w.NBC, w.NTW, w.COT, w.coTiles, w.nPerBlock, w.nTiles, w.XCH, w.TH, w.TW, w.DP, w.tilesY, w.tilesX, w.S,
-             w.lds_bytes);
+             w.quad, w.lds_bytes);
     return MPA_OK;
   }
   FwdPlan f;
@@ -1250,6 +1269,7 @@ int mpa_conv2d_bwd_weight(const mpa_conv_desc* d, const float* x, const float* d
   p.TX64 = (int)(mpa_cdiv((long)pl.XCH * pl.XCHP, 64) * 64);
   p.TD64 = (int)(mpa_cdiv((long)pl.COT * pl.DCP, 64) * 64);
   p.with_bias = 1;
+  p.quad = pl.quad; p.xshift = pl.xshift;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)pl.S, (unsigned)pl.nTiles, (unsigned)pl.coTiles);
   if (pl.NBC == 1) MPA_LAUNCH((conv_wgrad_kernel<1, 16>), grid, dim3(256), pl.lds_bytes, s, p);
