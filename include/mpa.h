@@ -89,10 +89,13 @@ int mpa_bn_relu_train_fwd(const float* x, const float* gamma, const float* beta,
 int mpa_bn_relu_eval_fwd(const float* x, const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float* y, float* save_mean /*nullable*/, float* save_invstd /*nullable*/,
                          int B, int C, int HW, float eps, int relu, void* stream);
-/* dx, dgamma, dbeta from dy (grad w.r.t. the post-ReLU output y). train!=0: batch-stat backward. */
-int mpa_bn_relu_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean,
-                    const float* save_invstd, float* dx, float* dgamma, float* dbeta, double* stats_ws,
-                    int B, int C, int HW, int relu, int train, void* stream);
+/* dx, dgamma, dbeta from dy (grad w.r.t. the post-ReLU output y). train!=0: batch-stat backward.
+ * ReLU mask: with beta != NULL it is recomputed from x with the forward's own arithmetic and y is never read
+ * (y may then be NULL); with beta == NULL it is y > 0.                                                          */
+int mpa_bn_relu_bwd(const float* dy, const float* x, const float* y /*nullable*/, const float* gamma,
+                    const float* beta /*nullable*/, const float* save_mean, const float* save_invstd, float* dx,
+                    float* dgamma, float* dbeta, double* stats_ws, int B, int C, int HW, int relu, int train,
+                    void* stream);
 
 /* ------------------------------------------------------------------ pooling / upsampling
  * nn.MaxPool2d (unet_cnns.py:511-526; basic_cnns.py:376,393; unet_cnns.py:2314): -inf padding, floor mode.

@@ -272,18 +272,19 @@ class BatchNormReLUFn(torch.autograd.Function):
                                          _p(save_mean), _p(save_invstd), B, C, H * W, BN_EPS, int(relu), _s()),
                  "mpa_bn_relu_eval_fwd")
         ctx.training, ctx.relu = bool(training), bool(relu)
-        ctx.save_for_backward(x, y, gamma, save_mean, save_invstd)
+        # the backward recomputes the ReLU mask from x (same arithmetic as the forward), so y is not kept alive here
+        ctx.save_for_backward(x, gamma, beta, save_mean, save_invstd)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, gamma, save_mean, save_invstd = ctx.saved_tensors
+        x, gamma, beta, save_mean, save_invstd = ctx.saved_tensors
         dy = _c(dy)
         B, C, H, W = x.shape
         dx = torch.empty_like(x)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         ws = torch.empty(2 * C, dtype=torch.float64, device=x.device)
-        _chk(_lib().mpa_bn_relu_bwd(_p(dy), _p(x), _p(y), _p(gamma), _p(save_mean), _p(save_invstd), _p(dx), _p(dgamma),
+        _chk(_lib().mpa_bn_relu_bwd(_p(dy), _p(x), None, _p(gamma), _p(beta), _p(save_mean), _p(save_invstd), _p(dx), _p(dgamma),
                                    _p(dbeta), ctypes.c_void_p(ws.data_ptr()), B, C, H * W, int(ctx.relu),
                                    int(ctx.training), _s()), "mpa_bn_relu_bwd")
         return dx, dgamma, dbeta, None, None, None, None, None, None
