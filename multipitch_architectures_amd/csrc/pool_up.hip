@@ -103,36 +103,28 @@ __global__ __launch_bounds__(256) void maxpool_fwd_plane_kernel(const float* __r
   }
 }
 
+// Scatter form inside one (b, c) plane: the gradient plane lives in LDS, every window adds its dy to its recorded argmax
+// with an LDS float atomic, then the plane is written out with contiguous stores -- one LDS operation per *window*
+// instead of kh*kw argmax tests per input element (13 for the head's 13x1 stride-1 pool).  Where several overlapping
+// windows share an argmax the order of the fp32 adds is not fixed.
 __global__ __launch_bounds__(256) void maxpool_bwd_plane_kernel(const float* __restrict__ dy, const int32_t* __restrict__ idx,
-                                                                float* __restrict__ dx, int H, int W, int OH, int OW,
-                                                                int kh, int kw, int sh, int sw, int ph, int pw) {
+                                                                float* __restrict__ dx, int n_in, int n_out) {
   extern __shared__ float plane[];
-  const int n_in = H * W, n_out = OH * OW;
-  float* g = plane;                         // dy plane
-  int32_t* am = (int32_t*)(plane + n_out);  // argmax plane
   const long pl = blockIdx.x;
+  for (int i = threadIdx.x; i < n_in; i += 256) plane[i] = 0.f;
+  __syncthreads();
+  const float* g = dy + pl * n_out;
+  const int32_t* am = idx + pl * n_out;
   for (int o = threadIdx.x; o < n_out; o += 256) {
-    g[o] = dy[pl * n_out + o];
-    am[o] = idx[pl * n_out + o];
+    const int t = am[o];
+    if (t >= 0 && t < n_in) atomicAdd(&plane[t], g[o]);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < n_in; i += 256) {
-    const int iy = i / W, ix = i - iy * W;
-    int oy_lo = (iy + ph - kh + 1 + sh - 1);
-    oy_lo = oy_lo <= 0 ? 0 : oy_lo / sh;
-    int oy_hi = (iy + ph) / sh;
-    if (oy_hi > OH - 1) oy_hi = OH - 1;
-    int ox_lo = (ix + pw - kw + 1 + sw - 1);
-    ox_lo = ox_lo <= 0 ? 0 : ox_lo / sw;
-    int ox_hi = (ix + pw) / sw;
-    if (ox_hi > OW - 1) ox_hi = OW - 1;
-    float s = 0.f;
-    for (int oy = oy_lo; oy <= oy_hi; ++oy)
-      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-        const int o = oy * OW + ox;
-        if (am[o] == i) s += g[o];
-      }
-    dx[pl * n_in + i] = s;
+  float* out = dx + pl * n_in;
+  if ((n_in & 3) == 0) {
+    for (int i = threadIdx.x * 4; i < n_in; i += 1024) *reinterpret_cast<float4*>(out + i) = *reinterpret_cast<const float4*>(plane + i);
+  } else {
+    for (int i = threadIdx.x; i < n_in; i += 256) out[i] = plane[i];
   }
 }
 
@@ -281,9 +273,9 @@ int mpa_maxpool2d_bwd(const float* dy, const int32_t* idx, float* dx, int B, int
   if (!dy || !idx || !dx) return MPA_ERR_ARG;
   const int OH = (H + 2 * ph - kh) / sh + 1, OW = (W + 2 * pw - kw) / sw + 1;
   const long planes = (long)B * C;
-  if ((size_t)OH * OW * 8 <= PLANE_LDS_BYTES && planes <= 0x7fffffffL) {
-    MPA_LAUNCH(maxpool_bwd_plane_kernel, dim3((unsigned)planes), dim3(256), (size_t)OH * OW * 8, (hipStream_t)stream, dy,
-               idx, dx, H, W, OH, OW, kh, kw, sh, sw, ph, pw);
+  if ((size_t)H * W * 4 <= PLANE_LDS_BYTES && planes <= 0x7fffffffL) {
+    MPA_LAUNCH(maxpool_bwd_plane_kernel, dim3((unsigned)planes), dim3(256), (size_t)H * W * 4, (hipStream_t)stream, dy,
+               idx, dx, H * W, OH * OW);
     return mpa_launch_status();
   }
   MPA_LAUNCH(maxpool_bwd_kernel, dim3(row_blocks(planes * H)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx,
