@@ -133,7 +133,13 @@ def _check_train(name, B, T):
 F64_CASES = [c for c in CASES if "y64" in load_golden(*c).files]
 
 
-@pytest.mark.parametrize("case", [c for c in F64_CASES if c not in SLOW and not c[0].endswith((":L", ":XL", ":XXL"))], ids=_ids)
+# (tiny:SAUnet, B=50) is left to the fp32 tests: its float64 forward alone takes >1 min on 8 cores, and B=25 already pins
+# the batch-axis attention in float64 (forward *and* gradients)
+F64_SKIP = {("tiny:SAUnet", 50, 75)}
+
+
+@pytest.mark.parametrize("case", [c for c in F64_CASES if c not in SLOW and c not in F64_SKIP
+                                  and not c[0].endswith((":L", ":XL", ":XXL"))], ids=_ids)
 def test_oracle_float64_is_exactly_the_reference(case):
     """In float64 rounding noise vanishes: the restatement must reproduce the reference's forward, loss and every
     parameter gradient to ~1e-10 -- this is what pins the oracle's *algorithm* (batch-axis attention, double
