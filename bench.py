@@ -262,7 +262,7 @@ def main():
                                    f"(upconv4.double_conv.4), local batch {B_loc}", "launch_ms": kms,
                          "launches_timed": len(probe_ms), "algorithmic_gflop_per_launch": kflops / 1e9},
         }
-        if args.config in TRAIN_GFLOP_PER_PATCH:
+        if args.config in TRAIN_GFLOP_PER_PATCH and args.frames == 75:     # the FLOP table is for T = 75 patches
             step_tflops = TRAIN_GFLOP_PER_PATCH[args.config] * patches_per_s / 1e3
             out["step_tflops"] = step_tflops
             out["step_mfma_frac"] = step_tflops / (PEAK_FP32_MFMA_TFLOPS * world)
