@@ -189,13 +189,13 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const float* __restrict_
 // B*Cs*Hs skip rows, then the B*C1*H1 rows of dx1.
 __global__ __launch_bounds__(256) void upcat_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx1,
                                                         float* __restrict__ dskip, int B, int C1, int H1, int W1, int Cs,
-                                                        int Hs, int Ws) {
+                                                        int Hs, int Ws, long row0) {
   const int Ct = Cs + C1;
   const int UH = 2 * H1, UW = 2 * W1;
   const int padT = (Hs - UH) / 2, padL = (Ws - UW) / 2;
   const long rskip = (long)B * Cs * Hs, rx1 = (long)B * C1 * H1;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (long r = (long)blockIdx.x * 4 + wave; r < rskip + rx1; r += (long)gridDim.x * 4) {
+  for (long r = row0 + (long)blockIdx.x * 4 + wave; r < rskip + rx1; r += (long)gridDim.x * 4) {
     if (r < rskip) {
       const long b = r / ((long)Cs * Hs), rem = r - b * ((long)Cs * Hs);
       const float* src = dout + (b * Ct * Hs + rem) * Ws;
@@ -241,6 +241,20 @@ __global__ __launch_bounds__(256) void upcat_bwd_kernel(const float* __restrict_
       }
       dx1[k * W1 + j] = s;
     }
+  }
+}
+
+// dskip = dout[:, :Cs] (contiguous per sample): plain 16-byte copy, one workgroup row per (b, chunk)
+__global__ __launch_bounds__(256) void upcat_bwd_skip_kernel(const float* __restrict__ dout, float* __restrict__ dskip, long per_b_skip,
+                                                             long per_b_out) {
+  const long b = blockIdx.y;
+  const float* src = dout + b * per_b_out;
+  float* dst = dskip + b * per_b_skip;
+  if ((per_b_skip & 3) == 0 && (per_b_out & 3) == 0) {
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < per_b_skip; i += (long)gridDim.x * 1024)
+      *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(src + i);
+  } else {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per_b_skip; i += (long)gridDim.x * 256) dst[i] = src[i];
   }
 }
 
@@ -294,9 +308,22 @@ int mpa_upcat_fwd(const float* x1, const float* skip, float* out, int B, int C1,
 int mpa_upcat_bwd(const float* dout, float* dx1, float* dskip, int B, int C1, int H1, int W1, int Cs, int Hs, int Ws,
                   void* stream) {
   if (!dout || !dx1 || !dskip) return MPA_ERR_ARG;
+  if (((long)Cs * Hs * Ws) % 4 == 0 && ((long)(Cs + C1) * Hs * Ws) % 4 == 0) {
+    // the skip half is a contiguous slab per sample: 16-byte copy; the gather kernel then only walks the dx1 rows
+    // (an LDS-atomic scatter form was tried for dx1 and is 2x slower: neighbouring upsampled pixels share their source
+    // pixels, so the atomics of a wave collide)
+    const long per_b_skip = (long)Cs * Hs * Ws, per_b_out = (long)(Cs + C1) * Hs * Ws;
+    const unsigned bx = (unsigned)std::max<long>(1, std::min<long>(mpa_cdiv(per_b_skip, 1024), 1024));
+    MPA_LAUNCH(upcat_bwd_skip_kernel, dim3(bx, (unsigned)B), dim3(256), 0, (hipStream_t)stream, dout, dskip, per_b_skip,
+               per_b_out);
+    const long rskip = (long)B * Cs * Hs, rx1 = (long)B * C1 * H1;
+    MPA_LAUNCH(upcat_bwd_kernel, dim3(row_blocks(rx1)), dim3(256), 0, (hipStream_t)stream, dout, dx1, dskip, B, C1, H1, W1,
+               Cs, Hs, Ws, rskip);
+    return mpa_launch_status();
+  }
   const long n = (long)B * Cs * Hs + (long)B * C1 * H1;
   MPA_LAUNCH(upcat_bwd_kernel, dim3(row_blocks(n)), dim3(256), 0, (hipStream_t)stream, dout, dx1, dskip, B, C1, H1, W1,
-                     Cs, Hs, Ws);
+                     Cs, Hs, Ws, 0L);
   return mpa_launch_status();
 }
 
