@@ -25,6 +25,7 @@ namespace {
 
 // ------------------------------------------------------------------------------------------------ planning
 constexpr long FWD_LDS_BUDGET = 78 * 1024;   // two workgroups per CU (160 KiB LDS)
+constexpr int EDGE_MAXF = 3;                 // straddling quads (rows) per thread that edge_fix_* can carry (see there)
 
 struct FwdPlan {
   int NB, PB, TH, TW, tilesY, tilesX, CK, nChunks, IH, IW, LW, CHP, COT, COTP, coTiles, OH, OW, quad;
@@ -82,12 +83,13 @@ FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
           const int IH = (TH - 1) * sh + kh, IW = (TW - 1) * sw + kw;
           for (int lwi = 0; lwi < 2; ++lwi) {
             // row pitch == TW (mod 32) keeps pixel blocks that wrap a row conflict-free; fall back to the tight pitch.
-            // 16-byte LDS-DMA staging (quad): stride 1, W % 4 == 0, pitch % 4 == 0 and 3 spare columns for the
-            // 4-aligned window origin.
+            // 16-byte LDS-DMA staging (quad): stride 1, pitch % 4 == 0 and 3 spare columns for the 4-aligned window
+            // origin; when W % 4 != 0 the quad straddling the end of each row is completed by edge_fix_* (bounded
+            // number of such words per workgroup).
             int LW = (lwi == 0 && sw == 1 && kw - 1 <= 29) ? TW + 32 : (IW | 1);
             if (LW < IW) LW = IW | 1;
             int quad = 0;
-            if (sw == 1 && W % 4 == 0) {
+            if (sw == 1) {
               int lq = LW;
               if (lq % 4 != 0 || lq < IW + 3) lq = (int)mpa_cdiv(std::max(LW, IW + 3), 4) * 4;
               if (lwi == 1 || lq == LW) { LW = lq; quad = 1; }
@@ -104,6 +106,7 @@ FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
             while (CK > 4 && lds_words(CK) * 4 > 52 * 1024) CK /= 2;   // keep three workgroups per CU when the chunk allows
             const size_t lds = (size_t)lds_words(CK) * 4;
             if ((long)lds > FWD_LDS_BUDGET) continue;
+            if (quad && (W & 3) && ((long)CK * IH > 256 * EDGE_MAXF || KWS)) quad = 0;   // cannot fix up: dword staging
             // resident workgroups per CU: LDS and (estimated) VGPR limits
             const int regs = NB * PB * 4 + 4 * (NB + PB) + 48;
             const long bpc = std::max<long>(1, std::min<long>(std::min<long>(4, (160 * 1024) / (long)lds), 512 / regs));
@@ -276,6 +279,8 @@ __device__ __forceinline__ void glds_quad(const float* src, float* lds_dst_wave_
                                    (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, 0, 0);
 }
 
+// EF (edge fix): W % 4 != 0 -- see edge_fix_*; compiled separately so that the common aligned case keeps its leaner loop
+template <bool EF = false>
 __device__ __forceinline__ void glds_stage_x16(float* __restrict__ dst, const float* __restrict__ src, int lane, int wave,
                                                int nch, int nrows, int lw, int chp, int total64, int c0, int y0, int x0a,
                                                int C, int H, int W) {
@@ -291,17 +296,29 @@ __device__ __forceinline__ void glds_stage_x16(float* __restrict__ dst, const fl
     int iy, q;
     fast_divmod(r, lw4, inv, iy, q);
     const int gy = y0 + iy, gx = x0a + 4 * q;
-    const int ok = (int)(ch < cmax) & (int)(r < used4) & (int)((unsigned)gy < (unsigned)H) & (int)((unsigned)gx < (unsigned)W);
-    const int off = (c0 + ch) * HW + gy * W + gx;
-    if (base + lane < total4)       // the image is a multiple of 16 float4, not of 64: never spill into the next region
-      glds_quad(ok ? src + off : zsrc, dst + (long)base * 4);
+    if constexpr (EF) {
+      // x0a is a multiple of 4 whenever it is negative, so gx >= 0 covers the left edge.  A quad that straddles the
+      // right edge of its row is *not written here at all* (no DMA, so nothing can land late on top of it):
+      // edge_fix_* owns it.
+      const int rowok = (int)(ch < cmax) & (int)(r < used4) & (int)((unsigned)gy < (unsigned)H) & (int)(gx >= 0);
+      const int full = rowok & (int)(gx + 3 < W);
+      const int part = rowok & (int)(gx < W) & (int)(gx + 3 >= W);
+      const int off = (c0 + ch) * HW + gy * W + gx;
+      if (base + lane < total4 && !part) glds_quad(full ? src + off : zsrc, dst + (long)base * 4);
+    } else {
+      const int ok = (int)(ch < cmax) & (int)(r < used4) & (int)((unsigned)gy < (unsigned)H) & (int)((unsigned)gx < (unsigned)W);
+      const int off = (c0 + ch) * HW + gy * W + gx;
+      if (base + lane < total4)       // the image is a multiple of 16 float4, not of 64: never spill into the next region
+        glds_quad(ok ? src + off : zsrc, dst + (long)base * 4);
+    }
     r += 256;
     while (r >= chp4) { r -= chp4; ch += 1; }
   }
 }
 
-// dY image [nco][dcp]: first th*dp words per cout are rows (py) of dp words; dp % 4 == 0, dcp % 4 == 0, OW % 4 == 0,
-// x0 % 4 == 0, xlim % 4 == 0
+// dY image [nco][dcp]: first th*dp words per cout are rows (py) of dp words; dp % 4 == 0, dcp % 4 == 0.  The global side
+// needs no alignment (16-byte LDS-DMA accepts any 4-byte aligned address); a quad straddling xlim is zero-filled here and
+// completed by edge_fix_*
 __device__ __forceinline__ void glds_stage_dy16(float* __restrict__ dst, const float* __restrict__ src, int lane, int wave,
                                                 int nco, int th, int dp, int dcp, int total64, int c0, int y0, int x0, int C,
                                                 int OH, int OW, int xlim) {
@@ -317,7 +334,7 @@ __device__ __forceinline__ void glds_stage_dy16(float* __restrict__ dst, const f
     int py, q;
     fast_divmod(r, dp4, inv, py, q);
     const int oy = y0 + py, ox = x0 + 4 * q;
-    const int ok = (int)(co < cmax) & (int)(r < n4) & (int)(oy < OH) & (int)(ox < xlim);
+    const int ok = (int)(co < cmax) & (int)(r < n4) & (int)(oy < OH) & (int)(ox + 3 < xlim);
     const int off = (c0 + co) * plane + oy * OW + ox;
     if (base + lane < total4)
       glds_quad(ok ? src + off : zsrc, dst + (long)base * 4);
@@ -354,8 +371,48 @@ struct ConvFwdParams {
   int coTiles, nTilesAll;   // cout tiles; pixel tiles over the whole batch
 };
 
+// The one quad per row that straddles the right limit `xend` of the readable columns is skipped by the 16-byte stager;
+// edge_fix_load fetches its in-range words with ordinary loads (issued next to the DMA, so they share its latency) and
+// edge_fix_store writes the whole quad (in-range words + zeros) as one 16-byte LDS store after s_waitcnt vmcnt(0).
+// Image layout as in the stagers: row (ch, iy) starts at ch*chp + iy*lw; global row at (c0+ch)*H*Wg + gy*Wg.
+struct EdgeFix {
+  float4 v[EDGE_MAXF];
+  int off[EDGE_MAXF];
+};
+__device__ __forceinline__ void edge_fix_load(EdgeFix& f, const float* __restrict__ src, int tid, int nch, int nrows, int lw,
+                                              int chp, int c0, int y0, int x0, int C, int H, int Wg, int xend) {
+  const int span = xend - x0;
+  const int nvalid = span & 3;
+  const bool any = span > 0 && span < lw && nvalid != 0;
+  const int items = any ? nch * nrows : 0;     // one straddling quad per staged row
+  const int lcol = span & ~3;                  // its first column inside the window
+  const int cmax = min(nch, C - c0);
+#pragma unroll
+  for (int j = 0; j < EDGE_MAXF; ++j) {
+    const int e = tid + 256 * j;
+    f.off[j] = -1;
+    f.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < items) {
+      const int ch = e / nrows, iy = e - ch * nrows;
+      const int gy = y0 + iy;
+      if (ch < cmax && (unsigned)gy < (unsigned)H) {     // same row test as the stager's `rowok`
+        f.off[j] = ch * chp + iy * lw + lcol;
+        const float* g = src + (long)(c0 + ch) * H * Wg + (long)gy * Wg + x0 + lcol;
+        f.v[j].x = g[0];
+        if (nvalid > 1) f.v[j].y = g[1];
+        if (nvalid > 2) f.v[j].z = g[2];
+      }
+    }
+  }
+}
+__device__ __forceinline__ void edge_fix_store(const EdgeFix& f, float* __restrict__ dst) {
+#pragma unroll
+  for (int j = 0; j < EDGE_MAXF; ++j)
+    if (f.off[j] >= 0) *reinterpret_cast<float4*>(dst + f.off[j]) = f.v[j];
+}
+
 // ------------------------------------------------------------------------------------------------ forward kernel
-template <int NB, int PB, int KW = 0>
+template <int NB, int PB, int KW = 0, bool EF = false>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lds_in = lds;
@@ -409,19 +466,23 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
   const float* wtile = p.wp + (long)cot * p.nChunks * p.kh * slab;
   const int astep = p.CK * p.COTP;
 
+  EdgeFix efix;            // only live in the EF instantiations
+  (void)efix;
   const bool split = gridDim.z > 1;
   const int c_begin = blockIdx.z * p.chunksPer, c_end = min(p.nChunks, c_begin + p.chunksPer);
   for (int c = c_begin; c < c_end; ++c) {
     __syncthreads();   // every wave is done with the previous chunk's tile and slabs
     const bool do_stage = (p.dbg != 1 && p.dbg != 3) || c == c_begin;
     if (do_stage) {
-      if (p.quad)
-        glds_stage_x16(lds_in, xb, lane, wave, p.CK, p.IH, p.LW, p.CHP, p.IN64, c * p.CK, iy0, x0a, p.Cin, p.H, p.W);
-      else
+      if (p.quad) {
+        glds_stage_x16<EF>(lds_in, xb, lane, wave, p.CK, p.IH, p.LW, p.CHP, p.IN64, c * p.CK, iy0, x0a, p.Cin, p.H, p.W);
+        if constexpr (EF) edge_fix_load(efix, xb, tid, p.CK, p.IH, p.LW, p.CHP, c * p.CK, iy0, x0a, p.Cin, p.H, p.W, p.W);
+      } else
         glds_stage_x(lds_in, xb, lane, wave, p.CK, p.IH, p.IW, p.LW, p.CHP, p.IN64, c * p.CK, iy0, ix0, p.Cin, p.H, p.W);
       glds_copy16(lds_w0, wtile + (long)(c * p.kh) * slab, tid, slab / 4);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (EF) { if (p.quad && do_stage) edge_fix_store(efix, lds_in); }
     __syncthreads();
     for (int dy = 0; dy < p.kh; ++dy) {
       const float* lds_w = lds_w0 + (dy & 1) * p.SL64;
@@ -567,15 +628,25 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
   }
 }
 
-template <int NB, int PB, int KW>
-int launch_fwd_one(const FwdPlan& pl, const ConvFwdParams& p, dim3 grid, hipStream_t s) {
+template <int NB, int PB, int KW, bool EF>
+int launch_fwd_ef(const FwdPlan& pl, const ConvFwdParams& p, dim3 grid, hipStream_t s) {
   static bool big_lds = false;
   if (!big_lds) {
-    (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<NB, PB, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<NB, PB, KW, EF>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     big_lds = true;
   }
-  MPA_LAUNCH((conv_fwd_kernel<NB, PB, KW>), grid, dim3(256), pl.lds_bytes, s, p);
+  MPA_LAUNCH((conv_fwd_kernel<NB, PB, KW, EF>), grid, dim3(256), pl.lds_bytes, s, p);
   return mpa_launch_status();
+}
+
+template <int NB, int PB, int KW>
+int launch_fwd_one(const FwdPlan& pl, const ConvFwdParams& p, dim3 grid, hipStream_t s) {
+  // the edge-fix build only for the generic tap loop: the kw-specialised kernels serve 15x15 / 9x9 layers at widths
+  // 216 and 108, and their register budget is tight
+  if constexpr (KW == 0) {
+    if (p.quad && (p.W & 3)) return launch_fwd_ef<NB, PB, KW, true>(pl, p, grid, s);
+  }
+  return launch_fwd_ef<NB, PB, KW, false>(pl, p, grid, s);
 }
 
 template <int NB, int PB>

@@ -20,5 +20,5 @@ for k,p in model.named_parameters():
     mine=p.grad.detach().cpu().numpy().ravel()[sample_idx(p.numel(),16)].astype(np.float64)
     r64=g[f'grad64.{k}.samples']; r32=g[f'grad.{k}.samples'].astype(np.float64); sc=float(g[f'grad64.{k}.absmax'])
     rows.append((np.abs(mine-r64).max()/max(sc,1e-30), np.abs(r32-r64).max()/max(sc,1e-30), sc, k))
-rows.sort(reverse=True)
-for r in rows[:25]: print('%.2e ref %.2e scale %.2e %s'%r)
+print('in registration order (output side last):')
+for r in rows: print('%.2e ref %.2e scale %.2e %s'%r)
