@@ -319,6 +319,7 @@ __device__ __forceinline__ void glds_stage_x16(float* __restrict__ dst, const fl
 // dY image [nco][dcp]: first th*dp words per cout are rows (py) of dp words; dp % 4 == 0, dcp % 4 == 0.  The global side
 // needs no alignment (16-byte LDS-DMA accepts any 4-byte aligned address); a quad straddling xlim is zero-filled here and
 // completed by edge_fix_*
+template <bool EF = false>
 __device__ __forceinline__ void glds_stage_dy16(float* __restrict__ dst, const float* __restrict__ src, int lane, int wave,
                                                 int nco, int th, int dp, int dcp, int total64, int c0, int y0, int x0, int C,
                                                 int OH, int OW, int xlim) {
@@ -334,9 +335,11 @@ __device__ __forceinline__ void glds_stage_dy16(float* __restrict__ dst, const f
     int py, q;
     fast_divmod(r, dp4, inv, py, q);
     const int oy = y0 + py, ox = x0 + 4 * q;
-    const int ok = (int)(co < cmax) & (int)(r < n4) & (int)(oy < OH) & (int)(ox + 3 < xlim);
+    const int rowok = (int)(co < cmax) & (int)(r < n4) & (int)(oy < OH);
+    const int ok = rowok & (int)(ox + 3 < xlim);
+    const int part = EF ? (rowok & (int)(ox < xlim) & (int)(ox + 3 >= xlim)) : 0;   // left to edge_fix_* (see there)
     const int off = (c0 + co) * plane + oy * OW + ox;
-    if (base + lane < total4)
+    if (base + lane < total4 && !part)
       glds_quad(ok ? src + off : zsrc, dst + (long)base * 4);
     r += 256;
     while (r >= dcp4) { r -= dcp4; co += 1; }
@@ -766,6 +769,7 @@ struct WgPlan {
   size_t lds_bytes;
   bool ok;
   int quad, xshift;   // 16-byte LDS-DMA staging: 4-aligned window origin (x0a = ix0 - xshift), pitches % 4 == 0
+  int ef;             // row ends are not quad aligned: edge_fix_* completes the straddling quads
 };
 
 WgPlan plan_wgrad(const mpa_conv_desc* d) {
@@ -791,11 +795,16 @@ WgPlan plan_wgrad(const mpa_conv_desc* d) {
     static const int force_txn = getenv("MPA_WG_TXN") ? atoi(getenv("MPA_WG_TXN")) : 0;   // diagnostics
     for (int txn = 1; txn <= std::min(OW, 64); ++txn) {
       if (force_txn && txn != std::min(force_txn, OW)) continue;
-      const int TW = (int)mpa_cdiv(OW, txn);
+      int TW = (int)mpa_cdiv(OW, txn);
       const int DP = (int)mpa_cdiv(TW, 4) * 4;
       const int IW = (DP - 1) * d->sw + d->kw;
-      // 16-byte LDS-DMA staging needs stride 1, W and OW multiples of 4 and tile origins on multiples of 4
-      const int quad = (d->sw == 1 && d->W % 4 == 0 && OW % 4 == 0 && (TW % 4 == 0 || txn == 1)) ? 1 : 0;
+      // 16-byte LDS-DMA staging: stride 1 and tile origins on multiples of 4 (the tile width is rounded up for that;
+      // the global side needs no alignment).  Row ends that are not quad aligned are completed by edge_fix_*.
+      const int quad = d->sw == 1 ? 1 : 0;
+      if (quad && txn > 1) TW = DP;
+      const int tilesX = (int)mpa_cdiv(OW, TW);
+      if (quad && tilesX != txn) continue;                  // the same tiling is reached from a smaller txn
+      const int ef = quad && ((d->W & 3) || (OW & 3)) ? 1 : 0;
       const int xshift = quad ? ((-d->pw) % 4 + 4) % 4 : 0;
       const int LW = quad ? (int)mpa_cdiv(IW + 3, 4) * 4 : (IW | 1);
       for (int TH = std::min(OH, 64); TH >= 1; --TH) {
@@ -804,6 +813,7 @@ WgPlan plan_wgrad(const mpa_conv_desc* d) {
         const int DCP = round_mod(TH * DP, 32, quad ? 4 : 2);
         const long floats = mpa_cdiv((long)pl.XCH * XCHP, 64) * 64 + mpa_cdiv((long)pl.COT * DCP, 64) * 64;
         if (floats * 4 > 64 * 1024) continue;
+        if (ef && ((long)pl.XCH * IH > 256 * EDGE_MAXF || (long)pl.COT * TH > 256 * EDGE_MAXF)) continue;
         const int ty = (int)mpa_cdiv(OH, TH);
         // cycles per tile: MFMA issue (per wave) + staging.  An LDS-DMA wave instruction costs the CU ~80 cycles
         // whatever its width: 64 words (dword form) or 256 words (16-byte form) each, four waves issuing in turn.
@@ -818,7 +828,7 @@ WgPlan plan_wgrad(const mpa_conv_desc* d) {
           best = pl;
           best.TH = TH; best.TW = TW; best.DP = DP; best.tilesY = ty; best.tilesX = txn; best.IH = IH; best.IW = IW;
           best.LW = LW; best.XCHP = XCHP; best.DCP = DCP; best.lds_bytes = (size_t)floats * 4; best.ok = true;
-          best.quad = quad; best.xshift = xshift;
+          best.quad = quad; best.xshift = xshift; best.ef = ef;
         }
         break;   // largest TH that fits for this TW
       }
@@ -849,7 +859,7 @@ struct WgParams {
   int quad, xshift;
 };
 
-template <int NBC, int NTW>
+template <int NBC, int NTW, bool EF = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lds_x = lds;
@@ -891,10 +901,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgParams p) {
     __syncthreads();
     // dY tile: columns >= TW belong to the neighbouring tile -> clip the readable width at ox0+TW
     if (p.quad) {
-      glds_stage_x16(lds_x, p.x + (long)b * p.Cin * p.H * p.W, lane, wave, p.XCH, p.IH, p.LW, p.XCHP, p.TX64, ci_first,
-                     iy0, ix0 - p.xshift, p.Cin, p.H, p.W);
-      glds_stage_dy16(lds_dy, p.dy + (long)b * p.Cout * p.OH * p.OW, lane, wave, p.COT, p.TH, p.DP, p.DCP, p.TD64,
-                      cot * p.COT, oy0, ox0, p.Cout, p.OH, p.OW, min(p.OW, ox0 + p.TW));
+      const float* xb = p.x + (long)b * p.Cin * p.H * p.W;
+      const float* db_ = p.dy + (long)b * p.Cout * p.OH * p.OW;
+      const int xlim = min(p.OW, ox0 + p.TW);
+      glds_stage_x16<EF>(lds_x, xb, lane, wave, p.XCH, p.IH, p.LW, p.XCHP, p.TX64, ci_first, iy0, ix0 - p.xshift, p.Cin, p.H,
+                         p.W);
+      glds_stage_dy16<EF>(lds_dy, db_, lane, wave, p.COT, p.TH, p.DP, p.DCP, p.TD64, cot * p.COT, oy0, ox0, p.Cout, p.OH,
+                          p.OW, xlim);
+      if constexpr (EF) {
+        EdgeFix fx, fd;
+        edge_fix_load(fx, xb, tid, p.XCH, p.IH, p.LW, p.XCHP, ci_first, iy0, ix0 - p.xshift, p.Cin, p.H, p.W, p.W);
+        edge_fix_load(fd, db_, tid, p.COT, p.TH, p.DP, p.DCP, cot * p.COT, oy0, ox0, p.Cout, p.OH, p.OW, xlim);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        edge_fix_store(fx, lds_x);
+        edge_fix_store(fd, lds_dy);
+      }
     } else {
       glds_stage_x(lds_x, p.x + (long)b * p.Cin * p.H * p.W, lane, wave, p.XCH, p.IH, p.IW, p.LW, p.XCHP, p.TX64, ci_first,
                    iy0, ix0, p.Cin, p.H, p.W);
@@ -1268,9 +1289,9 @@ int mpa_conv2d_describe_plan(const mpa_conv_desc* d, int mode, char* buf, int bu
     }
     WgPlan w = plan_wgrad(d);
     if (!w.ok) return MPA_ERR_UNSUPPORTED;
-    snprintf(buf, buflen, "wgrad<%d,%d> COT=%d coTiles=%d nPerBlock=%d nTiles=%d XCH=%d tile=%dx%d (DP %d) tiles=%dx%d S=%d quad=%d lds=%zuB",
+    snprintf(buf, buflen, "wgrad<%d,%d> COT=%d coTiles=%d nPerBlock=%d nTiles=%d XCH=%d tile=%dx%d (DP %d) tiles=%dx%d S=%d quad=%d ef=%d lds=%zuB",
              w.NBC, w.NTW, w.COT, w.coTiles, w.nPerBlock, w.nTiles, w.XCH, w.TH, w.TW, w.DP, w.tilesY, w.tilesX, w.S,
-             w.quad, w.lds_bytes);
+             w.quad, w.ef, w.lds_bytes);
     return MPA_OK;
   }
   FwdPlan f;
@@ -1343,11 +1364,17 @@ int mpa_conv2d_bwd_weight(const mpa_conv_desc* d, const float* x, const float* d
   p.quad = pl.quad; p.xshift = pl.xshift;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)pl.S, (unsigned)pl.nTiles, (unsigned)pl.coTiles);
-  if (pl.NBC == 1) MPA_LAUNCH((conv_wgrad_kernel<1, 16>), grid, dim3(256), pl.lds_bytes, s, p);
-  else if (pl.NBC == 2 && pl.NTW == 16) MPA_LAUNCH((conv_wgrad_kernel<2, 16>), grid, dim3(256), pl.lds_bytes, s, p);
-  else if (pl.NBC == 2) MPA_LAUNCH((conv_wgrad_kernel<2, 8>), grid, dim3(256), pl.lds_bytes, s, p);
-  else if (pl.NBC == 4) MPA_LAUNCH((conv_wgrad_kernel<4, 6>), grid, dim3(256), pl.lds_bytes, s, p);
-  else MPA_LAUNCH((conv_wgrad_kernel<5, 6>), grid, dim3(256), pl.lds_bytes, s, p);
+#define MPA_WG_LAUNCH(NBC_, NTW_)                                                                            \
+  do {                                                                                                      \
+    if (pl.ef) MPA_LAUNCH((conv_wgrad_kernel<NBC_, NTW_, true>), grid, dim3(256), pl.lds_bytes, s, p);      \
+    else MPA_LAUNCH((conv_wgrad_kernel<NBC_, NTW_, false>), grid, dim3(256), pl.lds_bytes, s, p);           \
+  } while (0)
+  if (pl.NBC == 1) MPA_WG_LAUNCH(1, 16);
+  else if (pl.NBC == 2 && pl.NTW == 16) MPA_WG_LAUNCH(2, 16);
+  else if (pl.NBC == 2) MPA_WG_LAUNCH(2, 8);
+  else if (pl.NBC == 4) MPA_WG_LAUNCH(4, 6);
+  else MPA_WG_LAUNCH(5, 6);
+#undef MPA_WG_LAUNCH
   int rc = mpa_launch_status();
   if (rc) return rc;
   const long n = (long)d->Cout * (pl.Ntot + 1);
