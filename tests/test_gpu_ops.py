@@ -371,3 +371,52 @@ def test_transformer_layer_against_torch_modules(dev):
     _close(xg.grad, xr.grad, 1e-4)
     for k, p in layer.named_parameters():
         _close(p.grad, sd["L." + k].grad, 2e-4, k)
+
+
+def _fuzz_conv_cases(n=48, seed=20261003):
+    """random small problems: odd widths (16-byte staging with the row-end edge fix), channel counts that are not
+    multiples of the chunk size, strides, one-sided padding, batch sizes that trigger the channel split"""
+    import random
+    rnd = random.Random(seed)
+    out = []
+    while len(out) < n:
+        kh, kw = rnd.choice([(1, 1), (3, 3), (5, 5), (9, 9), (15, 15), (3, 1), (1, 5), (2, 5), (7, 3)])
+        sh, sw = rnd.choice([(1, 1), (1, 1), (1, 1), (1, 3), (2, 1)])
+        ph, pw = rnd.choice([(kh // 2, kw // 2), (0, 0), (kh // 2, 0), (1, kw // 2)])
+        H, W = rnd.randint(max(kh, 3), 40), rnd.randint(max(kw, 3), 60)
+        if (H + 2 * ph - kh) < 0 or (W + 2 * pw - kw) < 0:
+            continue
+        out.append((rnd.choice([1, 2, 3, 5, 33]), rnd.choice([1, 3, 4, 6, 16, 20, 37, 64]), H, W,
+                    rnd.choice([1, 2, 8, 16, 30, 48, 70]), kh, kw, sh, sw, ph, pw))
+    return out
+
+
+@pytest.mark.parametrize("case", _fuzz_conv_cases(), ids=lambda c: "x".join(map(str, c)))
+def test_conv2d_random_shapes(dev, case):
+    from multipitch_architectures_amd import ops
+    B, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw = case
+    x = _rand((B, Cin, H, W), 11)
+    w = _rand((Cout, Cin, kh, kw), 12, (2.0 / (Cin * kh * kw)) ** 0.5)
+    b = _rand((Cout,), 13, 0.1)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv2d(xr, wr, br, stride=(sh, sw), padding=(ph, pw))
+    gy = _rand(tuple(yr.shape), 14)
+    yr.backward(gy.double())
+    xg, wg, bg = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    have_dx = True
+    try:
+        y = ops.conv2d(xg, wg, bg, (sh, sw), (ph, pw), ops.ACT_NONE, 0.0)
+        y.backward(gy.to(dev))
+    except Exception as e:
+        # backward-data exists for stride 1 and for the head's stride == kernel width; other strides must be refused
+        # loudly (never computed wrongly) -- forward and backward-weight are still checked
+        assert "unsupported" in str(e).lower() and (sh, sw) != (1, 1), e
+        have_dx = False
+        xg, wg, bg = x.to(dev), w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+        y = ops.conv2d(xg, wg, bg, (sh, sw), (ph, pw), ops.ACT_NONE, 0.0)
+        y.backward(gy.to(dev))
+    _close(y, yr, 2e-5, "y")
+    if have_dx:
+        _close(xg.grad, xr.grad, 2e-5, "dx")
+    _close(wg.grad, wr.grad, 5e-5, "dw")
+    _close(bg.grad, br.grad, 5e-5, "db")
