@@ -1,0 +1,36 @@
+"""GPU: the experiment runner (data pipeline -> model -> loss -> optimiser -> early stopping -> evaluation) end to end on
+synthetic recordings: the loss goes down, the log lines have the scripts' format, the measures come out finite."""
+import re
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_runner_trains_and_tests_on_synthetic_recordings(tmp_path):
+    import importlib.util
+    import os
+    from multipitch_architectures_amd import experiment
+    spec = importlib.util.spec_from_file_location(
+        "run_experiment", os.path.join(os.path.dirname(os.path.dirname(__file__)), "experiments", "run_experiment.py"))
+    run = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(run)
+    torch.manual_seed(0)
+    model, criterion, cfg = experiment.build("tiny:CNN")
+    train_files = [run.synthetic_recording(6000, 100 + k) for k in range(3)]
+    val_files, test_files = [run.synthetic_recording(1500, 7)], [run.synthetic_recording(400, 8)]
+    lines = []
+    ckpt = str(tmp_path / "best.pt")
+    hist = experiment.train(model, criterion, train_files, val_files, lr=cfg["lr"], max_epochs=4, path_trained_model=ckpt,
+                            log=lines.append)
+    assert len(hist) == 4 and hist[-1][0] < 0.8 * hist[0][0] and hist[-1][1] < hist[0][1]     # both losses decrease
+    assert any(re.fullmatch(r"Epoch #\d+ finished\. Train Loss: \d\.\d{4}, Val Loss: \d\.\d{4} with lr: \d\.\d{5}", l)
+               for l in lines)
+    assert "  .... model of epoch 0 saved." in lines
+    model.load_state_dict(torch.load(ckpt))
+    mean, framewise = experiment.test(model, test_files, ["synthetic"], log=lines.append)
+    assert set(mean) == set(experiment.MEASURES) and all(np.isfinite(v) for v in mean.values())
+    assert 0.0 < mean["roc_auc_measure"] <= 1.0
+    assert any(l.startswith("Mean f_measure:   ") for l in lines) and any(l.startswith("Framewise ") for l in lines)
