@@ -89,7 +89,7 @@ FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
             int LW = (lwi == 0 && sw == 1 && kw - 1 <= 29) ? TW + 32 : (IW | 1);
             if (LW < IW) LW = IW | 1;
             int quad = 0;
-            if (sw == 1) {
+            {                      // (the window is a contiguous block of columns whatever the stride of the taps)
               int lq = LW;
               if (lq % 4 != 0 || lq < IW + 3) lq = (int)mpa_cdiv(std::max(LW, IW + 3), 4) * 4;
               if (lwi == 1 || lq == LW) { LW = lq; quad = 1; }
@@ -800,11 +800,12 @@ WgPlan plan_wgrad(const mpa_conv_desc* d) {
       const int IW = (DP - 1) * d->sw + d->kw;
       // 16-byte LDS-DMA staging: stride 1 and tile origins on multiples of 4 (the tile width is rounded up for that;
       // the global side needs no alignment).  Row ends that are not quad aligned are completed by edge_fix_*.
-      const int quad = d->sw == 1 ? 1 : 0;
+      const int quad = 1;      // the staged windows are contiguous column blocks whatever the stride of the taps
       if (quad && txn > 1) TW = DP;
       const int tilesX = (int)mpa_cdiv(OW, TW);
       if (quad && tilesX != txn) continue;                  // the same tiling is reached from a smaller txn
       const int ef = quad && ((d->W & 3) || (OW & 3)) ? 1 : 0;
+      // window origin ix0 = ox0*sw - pw with ox0 a multiple of 4: its misalignment is the same for every tile
       const int xshift = quad ? ((-d->pw) % 4 + 4) % 4 : 0;
       const int LW = quad ? (int)mpa_cdiv(IW + 3, 4) * 4 : (IW | 1);
       for (int TH = std::min(OH, 64); TH >= 1; --TH) {

@@ -168,12 +168,22 @@ class Conv2dFn(torch.autograd.Function):
 
 def conv2d(x, weight, bias, stride=(1, 1), padding=(0, 0), act=ACT_NONE, slope=0.0):
     stride, padding = tuple(stride), tuple(padding)
-    kh = weight.shape[2]
+    kh, kw = weight.shape[2], weight.shape[3]
     if kh > 1 and kh == x.shape[2] and padding[0] == 0 and x.is_contiguous() and weight.is_contiguous():
-        # full-height valid kernel (conv3's (75,1) on a 75-frame patch, unet_cnns.py:545): (ci,dy) are adjacent in
-        # NCHW, so the conv is a 1 x kw conv over Cin*kh channels -- pure views, no data movement
         B, C, H, W = x.shape
-        y = Conv2dFn.apply(x.view(B, C * H, 1, W), weight.view(weight.shape[0], C * kh, 1, weight.shape[3]), bias,
+        if kw == 1 and stride[1] == 1 and padding[1] == 0:
+            # full-height valid (kh,1) kernel -- conv3's (75,1) on a 75-frame patch (unet_cnns.py:545, basic_cnns.py:178):
+            # the output is one row per sample, y[b,co,0,w] = sum_k W2[co,k] X[b,k,w] with k = (ci,dy) adjacent in NCHW,
+            # i.e. a plain GEMM over the B*W output positions.  As a convolution it would run one 72-pixel tile per
+            # sample through 6000 input channels with a barrier per 32-channel chunk (3.5 ms at batch 256); as a GEMM
+            # (one transposing copy of x, 128-row tiles, split-K) it is ~10x faster.
+            x2 = transpose_last2(x.view(B, C * H, W))                      # (B, W, C*H)
+            y2 = linear(x2, weight.view(weight.shape[0], C * kh), bias)    # (B, W, Cout)
+            if act != ACT_NONE:
+                y2 = activation(y2, act, slope)
+            return transpose_last2(y2).view(B, weight.shape[0], 1, W)
+        # other full-height valid kernels: a 1 x kw conv over Cin*kh channels -- pure views, no data movement
+        y = Conv2dFn.apply(x.view(B, C * H, 1, W), weight.view(weight.shape[0], C * kh, 1, kw), bias,
                            (1, stride[1]), (0, padding[1]), act, slope)
         return y
     return Conv2dFn.apply(x, weight, bias, stride, padding, act, slope)
