@@ -40,7 +40,9 @@ struct FwdPlan {
 // the 16-cout kernels (each such instruction costs the SIMD about 4 of the 32 cycles an MFMA occupies).
 // Measured: +4..8 % for NB <= 2; the 64-cout tile (NB = 4, already at 1 operand read per 2.7 MFMAs) loses 5 % to the
 // extra live registers, so it keeps the tap-major layout.
-inline int fwd_kw_special(int kw, int NB, int PB) { return ((kw == 15 || kw == 9) && PB >= 4 && NB <= 2) ? kw : 0; }
+inline int fwd_kw_special(int kw, int NB, int PB) {
+  return ((kw == 15 || kw == 9) && PB >= 4 && (NB <= 2 || NB * PB <= 24)) ? kw : 0;   // <4,8> would need > 256 VGPRs
+}
 
 inline int round_mod(int v, int m, int r) {  // smallest x >= v with x % m == r
   int x = v + ((r - v % m) % m + m) % m;
@@ -654,7 +656,7 @@ int launch_fwd_one(const FwdPlan& pl, const ConvFwdParams& p, dim3 grid, hipStre
 
 template <int NB, int PB>
 int launch_fwd_kw(const FwdPlan& pl, const ConvFwdParams& p, dim3 grid, hipStream_t s) {
-  if constexpr (PB >= 4 && NB <= 2) {
+  if constexpr (PB >= 4 && (NB <= 2 || NB * PB <= 24)) {
     if (pl.KWS == 15) return launch_fwd_one<NB, PB, 15>(pl, p, grid, s);
     if (pl.KWS == 9) return launch_fwd_one<NB, PB, 9>(pl, p, grid, s);
   }
