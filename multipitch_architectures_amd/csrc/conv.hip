@@ -941,8 +941,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgParams p) {
     for (int py = 0; py < p.TH; ++py) {
       const float* ap = lds_dy + py * p.DP + aoff;
       const float* bp = lds_x + py * p.sh * p.LW;
+      int px0 = 0;
+      if (p.sw == 1) {
+        // four k-steps per trip with compile-time pixel offsets: one address VGPR per operand row and immediates for
+        // the 16 pixels instead of a pointer increment per read
+        for (; px0 + 16 <= p.DP; px0 += 16) {
+          const float* apx[NBC];
+          const float* bpx[NTW];
+#pragma unroll
+          for (int cb = 0; cb < NBC; ++cb) apx[cb] = ap + cb * 16 * p.DCP + px0;
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) bpx[t] = bp + xoff[t] + px0;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            float a[NBC], bv[NTW];
+#pragma unroll
+            for (int cb = 0; cb < NBC; ++cb) a[cb] = apx[cb][4 * u];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) bv[t] = bpx[t][4 * u];
+#pragma unroll
+            for (int cb = 0; cb < NBC; ++cb)
+#pragma unroll
+              for (int t = 0; t < NTW; ++t)
+                acc[cb][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb], bv[t], acc[cb][t], 0, 0, 0);
+          }
+        }
+      }
 #pragma unroll 2
-      for (int px0 = 0; px0 < p.DP; px0 += 4) {
+      for (; px0 < p.DP; px0 += 4) {
         float a[NBC], bv[NTW];
 #pragma unroll
         for (int cb = 0; cb < NBC; ++cb) a[cb] = ap[cb * 16 * p.DCP + px0];
