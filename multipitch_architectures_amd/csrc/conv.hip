@@ -822,7 +822,9 @@ WgPlan plan_wgrad(const mpa_conv_desc* d) {
         // whatever its width: 64 words (dword form) or 256 words (16-byte form) each, four waves issuing in turn.
         // per k-step: NBC*NTW MFMAs of 32 cycles plus ~2 non-MFMA vector instructions (read + address) per operand at
         // ~4 cycles each; per tile row: ~30 instructions of loop set-up (measured: 37x4 tiles ran 26 % slower than 8x36)
-        const double mfma = (double)TH * ((DP / 4) * (pl.NBC * pl.NTW * 32.0 + 8.0 * (pl.NBC + pl.NTW)) + 120.0);
+        // (rows of at least 16 pixels run the unrolled loop with immediate offsets: ~1 instead of ~2 such instructions)
+        const double opi = (d->sw == 1 && DP >= 16) ? 4.0 : 8.0;
+        const double mfma = (double)TH * ((DP / 4) * (pl.NBC * pl.NTW * 32.0 + opi * (pl.NBC + pl.NTW)) + 120.0);
         const double words = (double)pl.XCH * IH * LW + (double)pl.COT * TH * DP;
         const double stage = words / (quad ? 256.0 : 64.0) * 80.0;
         const double cost = (double)ty * txn * (mfma + 0.7 * stage + 600.0) * pad_eff;
