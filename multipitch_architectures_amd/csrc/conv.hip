@@ -63,8 +63,12 @@ FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
   // resident slots costs 5 rounds, not 4.1)
   const int nbs[4] = {1, 2, 4, 5};
   const int pbs[6] = {1, 2, 4, 6, 8, 12};
+  static const char* force = getenv("MPA_FWD_FORCE");          // diagnostics: "NB,PB" restricts the search
+  int fNB = 0, fPB = 0;
+  if (force) sscanf(force, "%d,%d", &fNB, &fPB);
   for (int ni = 0; ni < 4; ++ni) {
     const int NB = nbs[ni];
+    if (fNB && NB != fNB) continue;
     const int COT = NB * 16;
     const int coTiles = (int)mpa_cdiv(Cout, COT);
     if (ni > 0 && (long)coTiles * COT >= (long)mpa_cdiv(Cout, 16) * 16 + 32 && NB > 1) continue;   // too much cout padding
@@ -72,6 +76,7 @@ FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
     for (int pi = 0; pi < 6; ++pi) {
       if ((pbs[pi] == 12 && NB > 2) || (pbs[pi] == 8 && NB > 4)) continue;   // accumulator budget
       const int PB = pbs[pi], P = PB * 64;
+      if (fPB && PB != fPB) continue;
       for (int TH = 1; TH <= std::min(OH, P); ++TH) {
         const int TWmax = std::min(OW, P / TH);
         if (TWmax < 1) continue;

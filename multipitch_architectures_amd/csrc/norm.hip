@@ -450,10 +450,9 @@ int mpa_layernorm_cf_fwd(const float* x, const float* w, const float* b, float* 
   return mpa_launch_status();
 }
 
-// workspace: dw/db partials, LNCF_BWD_BLOCKS*2*C*F floats, carved from the tail of dw's caller-provided scratch:
-// the caller passes ws via dx==nullptr?  No: we keep it simple -- ws is allocated by the caller and passed through db's
-// neighbour.  See mpa_layernorm_cf_bwd_workspace().
-#define LN_BWD_BLOCKS 128
+// workspace (caller-allocated, mpa_layernorm_bwd_workspace bytes): one partial dgamma/dbeta row per workgroup, reduced
+// by reduce2_kernel in a fixed order
+#define LN_BWD_BLOCKS 1024   // workgroups of the row loop (each leaves one partial dgamma/dbeta row in the workspace)
 int64_t mpa_layernorm_bwd_workspace(int n) { return (int64_t)LN_BWD_BLOCKS * 2 * n * 4; }
 
 int mpa_layernorm_cf_bwd_ws(const float* dy, const float* x, const float* w, const float* mean, const float* rstd, float* dx,

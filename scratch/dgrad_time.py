@@ -6,7 +6,9 @@ lib = L.load()
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 B = 256
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-for (ci, co, H, W, k, mode) in [(16, 128, 75, 216, 15, 1), (16, 128, 75, 216, 15, 0), (16, 16, 75, 216, 15, 0), (32, 16, 75, 216, 15, 0)]:
+LAYERS = [(16, 128, 75, 216, 15, 1), (16, 128, 75, 216, 15, 0), (16, 16, 75, 216, 15, 0), (32, 16, 75, 216, 15, 0)]
+if len(sys.argv) > 1: LAYERS = [LAYERS[int(sys.argv[1])]]
+for (ci, co, H, W, k, mode) in LAYERS:
     d = L.ConvDesc(B, ci, H, W, co, k, k, 1, 1, k // 2, k // 2)
     buf = ctypes.create_string_buffer(512); lib.mpa_conv2d_describe_plan(ctypes.byref(d), mode, buf, 512)
     w = torch.randn(co, ci, k, k, device="cuda") * 0.02

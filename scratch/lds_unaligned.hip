@@ -5,14 +5,17 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef LSTRIDE
+#define LSTRIDE 4
+#endif
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float* out, int shift, int iters) {
-  __shared__ __attribute__((aligned(16))) float lds[8192];
-  for (int i = threadIdx.x; i < 8192; i += 256) lds[i] = (float)i;
+  __shared__ __attribute__((aligned(16))) float lds[8192 + 2048];
+  for (int i = threadIdx.x; i < 8192 + 2048; i += 256) lds[i] = (float)i;
   __syncthreads();
   const int lane = threadIdx.x & 63;
   float acc = 0.f;
-  unsigned addr = (unsigned)((lane + shift) * 4 + (threadIdx.x >> 6) * 4096);   // byte address: lane-consecutive floats
+  unsigned addr = (unsigned)((lane * LSTRIDE + shift) * 4 + (threadIdx.x >> 6) * 8192);   // byte address: lanes LSTRIDE floats apart
   for (int it = 0; it < iters; ++it) {
     // 4 independent requests of 4 floats each in flight, one wait
     if (MODE == 0) {
@@ -39,7 +42,7 @@ __global__ __launch_bounds__(256) void k(float* out, int shift, int iters) {
                    : "v"(addr) : "memory");
       acc += v[0][0] + v[0][1] + v[1][0] + v[1][1] + v[2][0] + v[4][0] + v[6][0];
     }
-    addr ^= 1024;
+    addr ^= 2048;
   }
   out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
@@ -59,7 +62,7 @@ void run(const char* name, int shift) {
   std::vector<float> h(256); hipMemcpy(h.data(), d, 1024, hipMemcpyDeviceToHost);
   int bad = 0;
   for (int t = 0; t < 256; ++t) {
-    int base = (t & 63) + shift + (t >> 6) * 1024;
+    int base = (t & 63) * LSTRIDE + shift + (t >> 6) * 2048;
     float want = (float)(4 * base + 6 + 3 * base + 16 + 32 + 48);
     if (h[t] != want) ++bad;
   }
