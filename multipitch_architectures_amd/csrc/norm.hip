@@ -108,13 +108,22 @@ __global__ __launch_bounds__(256) void layernorm_cf_bwd_kernel(const float* __re
   }
 }
 
-__global__ void reduce2_kernel(const float* __restrict__ ws, float* __restrict__ o0, float* __restrict__ o1, int n, int S) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n; i += gridDim.x * blockDim.x) {
-    const int which = i / n, k = i - which * n;
-    float s = 0.f;
-    for (int j = 0; j < S; ++j) s += ws[((long)j * 2 + which) * n + k];
-    (which ? o1 : o0)[k] = s;
+// ws [S][2][n] -> o0[n], o1[n].  One workgroup per 64 outputs: lane = output, the four waves take every fourth partial
+// row and are combined through LDS in a fixed order (deterministic, and S = 1024 rows are no longer one serial chain).
+__global__ __launch_bounds__(256) void reduce2_kernel(const float* __restrict__ ws, float* __restrict__ o0,
+                                                      float* __restrict__ o1, int n, int S) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  int which = 0, k = 0;
+  if (i < 2 * n) {
+    which = i / n; k = i - which * n;
+    for (int j = wave; j < S; j += 4) s += ws[((long)j * 2 + which) * n + k];
   }
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && i < 2 * n) (which ? o1 : o0)[k] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
 // ---------------------------------------------------------------------------------- LayerNorm over rows (E <= 512)
@@ -464,7 +473,7 @@ int mpa_layernorm_cf_bwd_ws(const float* dy, const float* x, const float* w, con
                      (float*)ws, B, C, T, F);
   int rc = mpa_launch_status();
   if (rc) return rc;
-  MPA_LAUNCH(reduce2_kernel, dim3((unsigned)mpa_cdiv(2 * n, 256)), dim3(256), 0, s, (const float*)ws, dw, db, n,
+  MPA_LAUNCH(reduce2_kernel, dim3((unsigned)mpa_cdiv(2 * n, 64)), dim3(256), 0, s, (const float*)ws, dw, db, n,
                      LN_BWD_BLOCKS);
   return mpa_launch_status();
 }
@@ -485,7 +494,7 @@ int mpa_layernorm_rows_bwd_ws(const float* dy, const float* xs, const float* w, 
                      dx, (float*)ws, (long)rows, E);
   int rc = mpa_launch_status();
   if (rc) return rc;
-  MPA_LAUNCH(reduce2_kernel, dim3((unsigned)mpa_cdiv(2 * E, 256)), dim3(256), 0, s, (const float*)ws, dw, db, E,
+  MPA_LAUNCH(reduce2_kernel, dim3((unsigned)mpa_cdiv(2 * E, 64)), dim3(256), 0, s, (const float*)ws, dw, db, E,
                      LN_BWD_BLOCKS);
   return mpa_launch_status();
 }
