@@ -41,7 +41,7 @@ struct FwdPlan {
 // Measured: +4..8 % for NB <= 2; the 64-cout tile (NB = 4, already at 1 operand read per 2.7 MFMAs) loses 5 % to the
 // extra live registers, so it keeps the tap-major layout.
 inline int fwd_kw_special(int kw, int NB, int PB) {
-  return ((kw == 15 || kw == 9) && PB >= 4 && (NB <= 2 || NB * PB <= 24)) ? kw : 0;   // <4,8> would need > 256 VGPRs
+  return ((kw == 15 || kw == 9 || kw == 5 || kw == 3) && PB >= 4 && (NB <= 2 || NB * PB <= 24)) ? kw : 0;   // <4,8> would need > 256 VGPRs
 }
 
 inline int round_mod(int v, int m, int r) {  // smallest x >= v with x % m == r
@@ -113,7 +113,7 @@ FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
             while (CK > 4 && lds_words(CK) * 4 > 52 * 1024) CK /= 2;   // keep three workgroups per CU when the chunk allows
             const size_t lds = (size_t)lds_words(CK) * 4;
             if ((long)lds > FWD_LDS_BUDGET) continue;
-            if (quad && (W & 3) && ((long)CK * IH > 256 * EDGE_MAXF || KWS)) quad = 0;   // cannot fix up: dword staging
+            if (quad && (W & 3) && ((long)CK * IH > 256 * EDGE_MAXF || KWS >= 9)) quad = 0;   // cannot fix up: dword staging
             // resident workgroups per CU: LDS and (estimated) VGPR limits
             const int regs = NB * PB * 4 + 4 * (NB + PB) + 48;
             const long bpc = std::max<long>(1, std::min<long>(std::min<long>(4, (160 * 1024) / (long)lds), 512 / regs));
@@ -651,9 +651,9 @@ int launch_fwd_ef(const FwdPlan& pl, const ConvFwdParams& p, dim3 grid, hipStrea
 
 template <int NB, int PB, int KW>
 int launch_fwd_one(const FwdPlan& pl, const ConvFwdParams& p, dim3 grid, hipStream_t s) {
-  // the edge-fix build only for the generic tap loop: the kw-specialised kernels serve 15x15 / 9x9 layers at widths
-  // 216 and 108, and their register budget is tight
-  if constexpr (KW == 0) {
+  // no edge-fix build for the 15x15 / 9x9 specialisations: they serve widths 216 and 108, and their register budget is
+  // tight
+  if constexpr (KW < 9) {
     if (p.quad && (p.W & 3)) return launch_fwd_ef<NB, PB, KW, true>(pl, p, grid, s);
   }
   return launch_fwd_ef<NB, PB, KW, false>(pl, p, grid, s);
@@ -664,6 +664,8 @@ int launch_fwd_kw(const FwdPlan& pl, const ConvFwdParams& p, dim3 grid, hipStrea
   if constexpr (PB >= 4 && (NB <= 2 || NB * PB <= 24)) {
     if (pl.KWS == 15) return launch_fwd_one<NB, PB, 15>(pl, p, grid, s);
     if (pl.KWS == 9) return launch_fwd_one<NB, PB, 9>(pl, p, grid, s);
+    if (pl.KWS == 5) return launch_fwd_one<NB, PB, 5>(pl, p, grid, s);
+    if (pl.KWS == 3) return launch_fwd_one<NB, PB, 3>(pl, p, grid, s);
   }
   if (pl.KWS != 0) return MPA_ERR_UNSUPPORTED;
   return launch_fwd_one<NB, PB, 0>(pl, p, grid, s);
