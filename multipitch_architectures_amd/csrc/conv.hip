@@ -627,8 +627,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
         float* dst;
         if (p.outCdiv >= p.Cout) {            // plain NCHW store (uniform branch)
           dst = p.y + (long)b * p.outBS + (long)co * p.outCS + (long)oy * p.outRS + ox;
-        } else {                              // stride-(1,kw) backward-data: cout' = (dx phase, cin)
-          const int q = co / p.outCdiv, cc = co - q * p.outCdiv;
+        } else {                              // stride-(1,kw) backward-data: cout' = cin*kw + dx phase, so that the kw
+          // phases of a pixel -- adjacent floats of dx -- are written by one workgroup (the three phase planes written
+          // by different workgroups were three partial passes over every cache line of dx)
+          const int cc = co / p.outXmul, q = co - cc * p.outXmul;
           dst = p.y + (long)b * p.outBS + (long)cc * p.outCS + (long)oy * p.outRS + (long)ox * p.outXmul + q;
         }
         if (split) atomicAdd(dst, v);         // channel slices accumulate into the zeroed output; activation follows
@@ -742,7 +744,7 @@ __global__ void conv_pack_kernel(const PackParams p) {
       } else if (!p.xphase) {
         v = p.w[(((long)ci * p.Cin_w + co) * p.kh_w + (p.kh_w - 1 - dy)) * p.kw_w + (p.kw_w - 1 - dx)];
       } else {
-        const int q = co / p.Cin_w, cc = co - q * p.Cin_w;   // q = dx phase
+        const int cc = co / p.kw_w, q = co - cc * p.kw_w;    // cout' = cin*kw + dx phase (see the epilogue)
         v = p.w[(((long)ci * p.Cin_w + cc) * p.kh_w + (p.kh_w - 1 - dy)) * p.kw_w + q];
       }
     }
