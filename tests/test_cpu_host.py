@@ -183,3 +183,37 @@ def test_data_and_metrics_have_no_cpu_path():
                         {"context": 75, "stride": 1, "compression": 10})
     with pytest.raises(RuntimeError):
         calculate_eval_measures(np.zeros((4, 72), np.float32), np.zeros((4, 72), np.float32), ["precision"])
+
+
+def test_planner_invariants_on_random_geometries():
+    """The planners are host code: for every stride-1 (and the head's stride == kernel width) geometry they must produce
+    a plan whose LDS footprint fits a CU, a positive packed-filter size for both pack modes and a positive workspace."""
+    import ctypes
+    import random
+    from multipitch_architectures_amd import _lib as L
+    lib = L.load()
+    rnd = random.Random(7)
+    seen = 0
+    for _ in range(300):
+        kh, kw = rnd.choice([(1, 1), (3, 3), (5, 5), (9, 9), (15, 15), (75, 1), (1, 61), (2, 5), (3, 1)])
+        sw = 3 if (kw == 3 and rnd.random() < 0.3) else 1
+        ph, pw = (kh // 2, 0 if sw == 3 else kw // 2) if rnd.random() < 0.7 else (0, 0)
+        H, W = rnd.randint(kh, 180), rnd.randint(max(kw, 3), 220)
+        if sw == 3:
+            W -= W % 3
+            if W < 3:
+                continue
+        B, Cin, Cout = rnd.choice([1, 2, 25, 32, 50, 256]), rnd.choice([1, 4, 6, 16, 30, 70, 128, 256]), rnd.choice([1, 8, 16, 50, 70, 128])
+        d = L.ConvDesc(B, Cin, H, W, Cout, kh, kw, 1, sw, ph, pw)
+        for mode in (0, 1, 2):
+            buf = ctypes.create_string_buffer(512)
+            rc = lib.mpa_conv2d_describe_plan(ctypes.byref(d), mode, buf, 512)
+            assert rc == 0, (d.key(), mode, rc)
+            text = buf.value.decode()
+            lds = int(re.search(r"lds=(\d+)B", text).group(1))
+            assert 0 < lds <= 80 * 1024, text
+        assert lib.mpa_conv2d_packed_floats(ctypes.byref(d), 0) > 0
+        assert lib.mpa_conv2d_packed_floats(ctypes.byref(d), 1) > 0
+        assert lib.mpa_conv2d_bwd_weight_workspace(ctypes.byref(d)) > 0
+        seen += 1
+    assert seen > 250
