@@ -197,6 +197,53 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     }
   }
   // D[m = kq*4 + r][n = l16]
+  // Wide epilogue (plain store, 16-byte aligned rows, whole 4-column groups): each 16-row slab of the wave tile goes
+  // through a wave-private LDS patch so that 16 / 8 lanes write one row's WN*16 contiguous floats as 16-byte stores --
+  // the scalar path writes 64-byte segments per row, which the memory system handles at a fraction of its store rate
+  // (the MLP's 13312 x 8192 outputs were bound by it).
+  constexpr int PW = WN * 16 + 4;                       // patch row pitch (floats)
+  const bool wide = !splitk && (p.ldc & 3) == 0 && (p.N & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 &&
+                    (!p.bias || (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0);
+  if (wide) {
+    __syncthreads();                                    // operand images are dead
+    static_assert(AF >= 4 * 16 * PW || BF >= 4 * 16 * PW, "epilogue patches must fit one operand image");
+    float* patch = (AF >= 4 * 16 * PW ? As : Bs) + wave * (16 * PW);   // 4 waves x 16 x PW floats
+    constexpr int C4 = WN * 4;                          // float4 per patch row
+    constexpr int RPI = 64 / C4;                        // rows written per store instruction
+    const int c4 = lane % C4, rr = lane / C4;
+    const int n = n0 + wn + c4 * 4;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) patch[(kq * 4 + r) * PW + j * 16 + l16] = acc[i][j][r];
+      __builtin_amdgcn_wave_barrier();
+      if (n < p.N) {
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll
+        for (int q = 0; q < 16 / RPI; ++q) {
+          const int row = q * RPI + rr;
+          const int m = m0 + wm + i * 16 + row;
+          if (m < p.M) {
+            float4 v = *reinterpret_cast<const float4*>(patch + row * PW + c4 * 4);
+            float* c = p.C + (long)m * p.ldc + n;
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            if (p.accumulate) {
+              const float4 o = *reinterpret_cast<const float4*>(c);
+              v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            v.x = mpa_apply_act(v.x, p.act, 0.f); v.y = mpa_apply_act(v.y, p.act, 0.f);
+            v.z = mpa_apply_act(v.z, p.act, 0.f); v.w = mpa_apply_act(v.w, p.act, 0.f);
+            *reinterpret_cast<float4*>(c) = v;
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < WM; ++i)
 #pragma unroll
