@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
   // Wide path (NB*PB > 16, plain NCHW target, TW % 4 == 0, OW % 4 == 0): every 16x16 accumulator tile is transposed
   // through a wave-private LDS patch so that a lane owns 4 consecutive pixels of one cout and writes one 16-byte store
   // -- 4x fewer store instructions (measured: the 128 dword stores per lane of <4,8> cost 6.4 % of the workgroup's life).
-  if (!split && NB * PB > 16 && p.outCdiv >= p.Cout && (p.TW & 3) == 0 && (p.OW & 3) == 0 && p.act != MPA_ACT_SIGMOID) {
+  if (!split && NB * PB >= 12 && p.outCdiv >= p.Cout && (p.TW & 3) == 0 && (p.OW & 3) == 0 && p.act != MPA_ACT_SIGMOID) {
     __syncthreads();                                  // the main loop's LDS images are dead now
     float* patch = lds + wave * (16 * 20);            // [cout 16][pixel 16 (+4 pad)]
     const int co_l = lane >> 2, quad = lane & 3;      // after the transpose: lane -> (cout row, 4-pixel group)
