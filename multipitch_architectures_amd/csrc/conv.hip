@@ -50,8 +50,10 @@ inline int round_mod(int v, int m, int r) {  // smallest x >= v with x % m == r
 }
 
 // allow_split: the launch may add channel slices atomically (backward-data only: the forward pass stays bit-reproducible)
+// phase: the launch stores through the (channel, phase) mapping -- only built for the generic and 15-tap loops, without
+// the row-end edge fix
 FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
-                 bool allow_split = false) {
+                 bool allow_split = false, bool phase = false) {
   FwdPlan best{};
   best.ok = false;
   const int OH = (H + 2 * ph - kh) / sh + 1, OW = (W + 2 * pw - kw) / sw + 1;
@@ -104,7 +106,9 @@ FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
             const int CHP = round_mod(IH * LW, 32, 16);
             int CK = 4;
             while (CK < 32 && CK < cin4 && kw * (CK / 4) < 15) CK *= 2;
-            const int KWS = fwd_kw_special(kw, NB, PB), KWP = (kw + 3) & ~3;
+            int KWS = fwd_kw_special(kw, NB, PB);
+            if (phase && KWS != 15) KWS = 0;
+            const int KWP = (kw + 3) & ~3;
             const int cotp = KWS ? COT : COTP;
             auto lds_words = [&](int ck) {
               const long slab = KWS ? (long)ck * COT * KWP : (long)kw * ck * COTP;
@@ -113,7 +117,7 @@ FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
             while (CK > 4 && lds_words(CK) * 4 > 52 * 1024) CK /= 2;   // keep three workgroups per CU when the chunk allows
             const size_t lds = (size_t)lds_words(CK) * 4;
             if ((long)lds > FWD_LDS_BUDGET) continue;
-            if (quad && (W & 3) && ((long)CK * IH > 256 * EDGE_MAXF || KWS >= 9)) quad = 0;   // cannot fix up: dword staging
+            if (quad && (W & 3) && ((long)CK * IH > 256 * EDGE_MAXF || KWS >= 9 || phase)) quad = 0;   // cannot fix up: dword staging
             // resident workgroups per CU: LDS and (estimated) VGPR limits
             const int regs = NB * PB * 4 + 4 * (NB + PB) + 48;
             const long bpc = std::max<long>(1, std::min<long>(std::min<long>(4, (160 * 1024) / (long)lds), 512 / regs));
@@ -377,6 +381,7 @@ struct ConvFwdParams {
   float slope;
   long outBS, outCS;   // output batch / channel strides (floats)
   int outRS, outXmul, outCdiv;
+  int outYmul, outH;   // phase stores: cout' = cin*(outXmul*outYmul) + v*outXmul + q -> row oy*outYmul+v (< outH), column ox*outXmul+q
   int chunksPer;       // input-channel chunks per blockIdx.z slice (== nChunks when the channels are not split)
   int coTiles, nTilesAll;   // cout tiles; pixel tiles over the whole batch
 };
@@ -422,7 +427,9 @@ __device__ __forceinline__ void edge_fix_store(const EdgeFix& f, float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------ forward kernel
-template <int NB, int PB, int KW = 0, bool EF = false>
+// PH (phase stores): backward-data variants whose couts are (channel, x/y phase) pairs -- a separate instantiation, as
+// EF is: the 16->128 forward sits on a register cliff and lost 10 % whenever either was compiled into the common kernel
+template <int NB, int PB, int KW = 0, bool EF = false, bool PH = false>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lds_in = lds;
@@ -578,7 +585,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
   // Wide path (NB*PB > 16, plain NCHW target, TW % 4 == 0, OW % 4 == 0): every 16x16 accumulator tile is transposed
   // through a wave-private LDS patch so that a lane owns 4 consecutive pixels of one cout and writes one 16-byte store
   // -- 4x fewer store instructions (measured: the 128 dword stores per lane of <4,8> cost 6.4 % of the workgroup's life).
-  if (!split && NB * PB >= 12 && p.outCdiv >= p.Cout && (p.TW & 3) == 0 && (p.OW & 3) == 0 && p.act != MPA_ACT_SIGMOID) {
+  if (!PH && !split && NB * PB >= 12 && p.outCdiv >= p.Cout && (p.TW & 3) == 0 && (p.OW & 3) == 0 && p.act != MPA_ACT_SIGMOID) {
     __syncthreads();                                  // the main loop's LDS images are dead now
     float* patch = lds + wave * (16 * 20);            // [cout 16][pixel 16 (+4 pad)]
     const int co_l = lane >> 2, quad = lane & 3;      // after the transpose: lane -> (cout row, 4-pixel group)
@@ -625,13 +632,17 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
         float v = acc[nb][pb][r];
         if (p.bias && blockIdx.z == 0) v += p.bias[co];
         float* dst;
-        if (p.outCdiv >= p.Cout) {            // plain NCHW store (uniform branch)
+        if constexpr (!PH) {                  // plain NCHW store
           dst = p.y + (long)b * p.outBS + (long)co * p.outCS + (long)oy * p.outRS + ox;
-        } else {                              // stride-(1,kw) backward-data: cout' = cin*kw + dx phase, so that the kw
-          // phases of a pixel -- adjacent floats of dx -- are written by one workgroup (the three phase planes written
-          // by different workgroups were three partial passes over every cache line of dx)
-          const int cc = co / p.outXmul, q = co - cc * p.outXmul;
-          dst = p.y + (long)b * p.outBS + (long)cc * p.outCS + (long)oy * p.outRS + (long)ox * p.outXmul + q;
+        } else {
+          // cout' = cin*(PX*PY) + v*PX + q: x phase q (stride-(1,kw) backward-data: the kw phases of a pixel are adjacent
+          // floats of dx, written by one workgroup) and/or y phase v (few-channel layers: V output rows per cout block)
+          const int nph = p.outXmul * p.outYmul;
+          const int cc = co / nph, phi = co - cc * nph;
+          const int vph = phi / p.outXmul, q = phi - vph * p.outXmul;
+          const int row = oy * p.outYmul + vph;
+          if (row >= p.outH) continue;
+          dst = p.y + (long)b * p.outBS + (long)cc * p.outCS + (long)row * p.outRS + (long)ox * p.outXmul + q;
         }
         if (split) atomicAdd(dst, v);         // channel slices accumulate into the zeroed output; activation follows
         else *dst = mpa_apply_act(v, p.act, p.slope);
@@ -640,14 +651,15 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
   }
 }
 
-template <int NB, int PB, int KW, bool EF>
+template <int NB, int PB, int KW, bool EF, bool PH = false>
 int launch_fwd_ef(const FwdPlan& pl, const ConvFwdParams& p, dim3 grid, hipStream_t s) {
   static bool big_lds = false;
   if (!big_lds) {
-    (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<NB, PB, KW, EF>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<NB, PB, KW, EF, PH>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              80 * 1024);
     big_lds = true;
   }
-  MPA_LAUNCH((conv_fwd_kernel<NB, PB, KW, EF>), grid, dim3(256), pl.lds_bytes, s, p);
+  MPA_LAUNCH((conv_fwd_kernel<NB, PB, KW, EF, PH>), grid, dim3(256), pl.lds_bytes, s, p);
   return mpa_launch_status();
 }
 
@@ -655,6 +667,10 @@ template <int NB, int PB, int KW>
 int launch_fwd_one(const FwdPlan& pl, const ConvFwdParams& p, dim3 grid, hipStream_t s) {
   // no edge-fix build for the 15x15 / 9x9 specialisations: they serve widths 216 and 108, and their register budget is
   // tight
+  if (p.outCdiv < p.Cout) {               // phase stores: built for the generic and the 15-tap loops only (plan_fwd)
+    if constexpr (KW == 0 || KW == 15) return launch_fwd_ef<NB, PB, KW, false, true>(pl, p, grid, s);
+    return MPA_ERR_UNSUPPORTED;
+  }
   if constexpr (KW < 9) {
     if (p.quad && (p.W & 3)) return launch_fwd_ef<NB, PB, KW, true>(pl, p, grid, s);
   }
@@ -711,6 +727,7 @@ struct PackParams {
   float* wp;
   int Cout_w, Cin_w, kh_w, kw_w;   // original filter dims
   int mode, xphase;                // xphase: strided-W backward (dx taken from co' / Cin)
+  int yphase;                      // V > 1: cout'' = cin*V + v with the flipped filter shifted down by v rows
   int CinP, CoutP, kh, kw;         // dims of the conv that will consume the packed filters
   int CK, nChunks, COT, COTP, coTiles;
   int KWP;                         // > 0: tap-vector layout packed[cot][chunk][dy][ck][COT][KWP] (see fwd_kw_special)
@@ -741,6 +758,10 @@ __global__ void conv_pack_kernel(const PackParams p) {
     if (col < p.COT && co < p.CoutP && ci < p.CinP && dx < p.kw) {
       if (p.mode == 0) {
         v = p.w[(((long)co * p.Cin_w + ci) * p.kh_w + dy) * p.kw_w + dx];
+      } else if (p.yphase > 1) {
+        const int cc = co / p.yphase, dyo = dy - (co - cc * p.yphase);
+        if (dyo >= 0 && dyo < p.kh_w)
+          v = p.w[(((long)ci * p.Cin_w + cc) * p.kh_w + (p.kh_w - 1 - dyo)) * p.kw_w + (p.kw_w - 1 - dx)];
       } else if (!p.xphase) {
         v = p.w[(((long)ci * p.Cin_w + co) * p.kh_w + (p.kh_w - 1 - dy)) * p.kw_w + (p.kw_w - 1 - dx)];
       } else {
@@ -755,16 +776,32 @@ __global__ void conv_pack_kernel(const PackParams p) {
 // derived problem for backward-data
 struct BwdDataGeom {
   bool ok, xphase;
-  int Cin, H, W, Cout, kh, kw, ph, pw;   // stride-1 conv consuming dy (B,Cin=Cout_orig,H=OH,W=OW)
+  int yphase;                            // V > 1: V output rows per derived cout block (see below)
+  int Cin, H, W, Cout, kh, kw, ph, pw;   // conv consuming dy (B,Cin=Cout_orig,H=OH,W=OW), stride (sh,1)
+  int sh, Hplan;                         // vertical stride V and the input height the planner must assume so that the
+                                         // derived conv has ceil(H_orig/V) output rows (rows past H are zero-filled)
 };
+
+// Stride-1 layers with very few input channels (the first conv: 6 HCQT harmonics) waste most of the 16-row MFMA tile in
+// backward-data (6 of 16 couts).  There the derived conv computes V vertically adjacent output rows at once:
+// cout'' = cin*V + v, kernel height kh+V-1 with the flipped filter shifted down by v rows, vertical stride V -- 12 of 16
+// rows busy for 16/15 of the taps (backward-data of inc.double_conv.0: 3.6 -> ~2 ms).
+inline int bwd_data_yphase(int Cin, int kh) {
+  if (kh < 5 || Cin > 8) return 1;
+  return (Cin <= 4 && kh >= 9) ? 4 : 2;
+}
 
 BwdDataGeom bwd_data_geom(const mpa_conv_desc* d) {
   BwdDataGeom g{};
   const int OH = (d->H + 2 * d->ph - d->kh) / d->sh + 1, OW = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
-  g.Cin = d->Cout; g.H = OH; g.W = OW;
+  g.Cin = d->Cout; g.H = OH; g.W = OW; g.yphase = 1; g.sh = 1; g.Hplan = OH;
   if (d->sh == 1 && d->sw == 1) {
     g.ok = true; g.xphase = false;
     g.Cout = d->Cin; g.kh = d->kh; g.kw = d->kw; g.ph = d->kh - 1 - d->ph; g.pw = d->kw - 1 - d->pw;
+    const int V = bwd_data_yphase(d->Cin, d->kh);
+    if (V > 1) {
+      g.yphase = V; g.sh = V; g.Cout = V * d->Cin; g.kh = d->kh + V - 1; g.Hplan = OH + V - 1;
+    }
   } else if (d->sh == 1 && d->sw == d->kw && d->pw == 0 && OW * d->sw == d->W) {
     g.ok = true; g.xphase = true;       // non-overlapping windows along W: kw independent (kh x 1) convs
     g.Cout = d->kw * d->Cin; g.kh = d->kh; g.kw = 1; g.ph = d->kh - 1 - d->ph; g.pw = 0;
@@ -772,6 +809,10 @@ BwdDataGeom bwd_data_geom(const mpa_conv_desc* d) {
     g.ok = false;
   }
   return g;
+}
+
+inline FwdPlan plan_bwd_data(const mpa_conv_desc* d, const BwdDataGeom& g) {
+  return plan_fwd(d->B, g.Cin, g.Hplan, g.W, g.Cout, g.kh, g.kw, g.sh, 1, g.ph, g.pw, true, g.xphase || g.yphase > 1);
 }
 
 // ------------------------------------------------------------------------------------------------ backward-weight
@@ -1229,15 +1270,16 @@ extern "C" {
 int64_t mpa_conv2d_packed_floats(const mpa_conv_desc* d, int mode) {
   if (!d) return MPA_ERR_ARG;
   FwdPlan pl;
+  int kh = d->kh, kw = d->kw;
   if (mode == 0) {
     pl = plan_fwd(d->B, d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw);
   } else {
     BwdDataGeom g = bwd_data_geom(d);
     if (!g.ok) return MPA_ERR_UNSUPPORTED;
-    pl = plan_fwd(d->B, g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw, true);
+    pl = plan_bwd_data(d, g);
+    kh = g.kh; kw = g.kw;
   }
   if (!pl.ok) return MPA_ERR_UNSUPPORTED;
-  const int kh = d->kh, kw = (mode == 1 && bwd_data_geom(d).xphase) ? 1 : d->kw;
   return (int64_t)pl.coTiles * pl.nChunks * kh * (pl.KWS ? pl.KWP : kw) * pl.CK * pl.COTP;
 }
 
@@ -1254,8 +1296,8 @@ int mpa_conv2d_pack(const mpa_conv_desc* d, int mode, const float* w, float* w_p
   } else {
     BwdDataGeom g = bwd_data_geom(d);
     if (!g.ok) return MPA_ERR_UNSUPPORTED;
-    pl = plan_fwd(d->B, g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw, true);
-    p.CinP = g.Cin; p.CoutP = g.Cout; p.kh = g.kh; p.kw = g.kw; p.xphase = g.xphase ? 1 : 0;
+    pl = plan_bwd_data(d, g);
+    p.CinP = g.Cin; p.CoutP = g.Cout; p.kh = g.kh; p.kw = g.kw; p.xphase = g.xphase ? 1 : 0; p.yphase = g.yphase;
   }
   if (!pl.ok) return MPA_ERR_UNSUPPORTED;
   p.CK = pl.CK; p.nChunks = pl.nChunks; p.COT = pl.COT; p.COTP = pl.COTP; p.coTiles = pl.coTiles;
@@ -1268,8 +1310,9 @@ int mpa_conv2d_pack(const mpa_conv_desc* d, int mode, const float* w, float* w_p
 
 static int conv_fwd_impl(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
                          const float* x, const float* wp, const float* bias, float* y, int act, float slope,
-                         long outBS, long outCS, int outRS, int outXmul, int outCdiv, hipStream_t s, bool allow_split = false) {
-  FwdPlan pl = plan_fwd(B, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, allow_split);
+                         long outBS, long outCS, int outRS, int outXmul, int outCdiv, hipStream_t s, bool allow_split = false,
+                         int Hplan = 0, int outYmul = 1, int outH = 0) {
+  FwdPlan pl = plan_fwd(B, Cin, Hplan ? Hplan : H, W, Cout, kh, kw, sh, sw, ph, pw, allow_split, outCdiv < Cout);
   if (!pl.ok) return MPA_ERR_UNSUPPORTED;
   ConvFwdParams p{};
   p.x = x; p.wp = wp; p.bias = bias; p.y = y;
@@ -1283,6 +1326,7 @@ static int conv_fwd_impl(int B, int Cin, int H, int W, int Cout, int kh, int kw,
   { const char* e = getenv("MPA_DEBUG_FWD"); p.dbg = e ? atoi(e) : 0; }
   p.act = act; p.slope = slope;
   p.outBS = outBS; p.outCS = outCS; p.outRS = outRS; p.outXmul = outXmul; p.outCdiv = outCdiv;
+  p.outYmul = outYmul; p.outH = outH ? outH : pl.OH;
   p.chunksPer = (int)mpa_cdiv(pl.nChunks, pl.KS);
   p.coTiles = pl.coTiles; p.nTilesAll = B * pl.tilesY * pl.tilesX;
   if (mpa_cdiv(pl.nChunks, p.chunksPer) <= 1) return launch_fwd(pl, p, s);
@@ -1309,6 +1353,12 @@ int mpa_conv2d_bwd_data(const mpa_conv_desc* d, const float* dy, const float* w_
   BwdDataGeom g = bwd_data_geom(d);
   if (!g.ok) return MPA_ERR_UNSUPPORTED;
   const long inBS = (long)d->Cin * d->H * d->W, inCS = (long)d->H * d->W;
+  if (g.yphase > 1) {
+    // V output rows per cout block: derived conv with vertical stride V; row oy*V + v of channel cout''/V
+    return conv_fwd_impl(d->B, g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, g.sh, 1, g.ph, g.pw, dy, w_packed, nullptr, dx,
+                         MPA_ACT_NONE, 0.f, inBS, inCS, d->W, 1, d->Cin, (hipStream_t)stream, true, g.Hplan, g.yphase,
+                         d->H);
+  }
   if (!g.xphase) {
     // output of the derived conv has size H x W again
     return conv_fwd_impl(d->B, g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw, dy, w_packed, nullptr, dx,
@@ -1339,7 +1389,7 @@ int mpa_conv2d_describe_plan(const mpa_conv_desc* d, int mode, char* buf, int bu
   else {
     BwdDataGeom g = bwd_data_geom(d);
     if (!g.ok) return MPA_ERR_UNSUPPORTED;
-    f = plan_fwd(d->B, g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw, true);
+    f = plan_bwd_data(d, g);
   }
   if (!f.ok) return MPA_ERR_UNSUPPORTED;
   snprintf(buf, buflen, "fwd<%d,%d> COT=%d coTiles=%d CK=%d chunks=%d tile=%dx%d tiles=%dx%d halo=%dx%d LW=%d quad=%d kwvec=%d ksplit=%d lds=%zuB",
