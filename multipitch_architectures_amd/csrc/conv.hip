@@ -52,8 +52,10 @@ inline int round_mod(int v, int m, int r) {  // smallest x >= v with x % m == r
 // allow_split: the launch may add channel slices atomically (backward-data only: the forward pass stays bit-reproducible)
 // phase: the launch stores through the (channel, phase) mapping -- only built for the generic and 15-tap loops, without
 // the row-end edge fix
+// phaseX == 3 (stride-(1,3) backward-data): 48-cout tiles = 16 channels x 3 phases, so that a workgroup owns whole
+// (channel, pixel) triples and can store them as contiguous 16-byte runs
 FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
-                 bool allow_split = false, bool phase = false) {
+                 bool allow_split = false, bool phase = false, int phaseX = 1) {
   FwdPlan best{};
   best.ok = false;
   const int OH = (H + 2 * ph - kh) / sh + 1, OW = (W + 2 * pw - kw) / sw + 1;
@@ -63,20 +65,22 @@ FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
   // cout blocking: all variants compete; the cost model charges padded couts, operand re-reads, and -- what decides
   // small batches / small images -- the number of *rounds* the grid needs on 256 CUs (a grid of 2112 workgroups on 512
   // resident slots costs 5 rounds, not 4.1)
-  const int nbs[4] = {1, 2, 4, 5};
+  const int nbs[5] = {1, 2, 4, 5, 3};
   const int pbs[6] = {1, 2, 4, 6, 8, 12};
   static const char* force = getenv("MPA_FWD_FORCE");          // diagnostics: "NB,PB" restricts the search
   int fNB = 0, fPB = 0;
   if (force) sscanf(force, "%d,%d", &fNB, &fPB);
-  for (int ni = 0; ni < 4; ++ni) {
+  for (int ni = 0; ni < 5; ++ni) {
     const int NB = nbs[ni];
     if (fNB && NB != fNB) continue;
+    if ((NB == 3) != (phase && phaseX == 3)) continue;      // 48-cout tiles exactly for the 3-phase stores
     const int COT = NB * 16;
     const int coTiles = (int)mpa_cdiv(Cout, COT);
     if (ni > 0 && (long)coTiles * COT >= (long)mpa_cdiv(Cout, 16) * 16 + 32 && NB > 1) continue;   // too much cout padding
     const int COTP = (COT % 32 == 0) ? COT + 16 : COT;   // filter-slab pitch == 16 (mod 32): conflict-free A reads
     for (int pi = 0; pi < 6; ++pi) {
       if ((pbs[pi] == 12 && NB > 2) || (pbs[pi] == 8 && NB > 4)) continue;   // accumulator budget
+      if (NB == 3 && (pbs[pi] < 4 || pbs[pi] > 8)) continue;                  // built for PB 4, 6, 8 only
       const int PB = pbs[pi], P = PB * 64;
       if (fPB && PB != fPB) continue;
       for (int TH = 1; TH <= std::min(OH, P); ++TH) {
@@ -107,7 +111,7 @@ FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
             int CK = 4;
             while (CK < 32 && CK < cin4 && kw * (CK / 4) < 15) CK *= 2;
             int KWS = fwd_kw_special(kw, NB, PB);
-            if (phase && KWS != 15) KWS = 0;
+            if ((phase && KWS != 15) || NB == 3) KWS = 0;
             const int KWP = (kw + 3) & ~3;
             const int cotp = KWS ? COT : COTP;
             auto lds_words = [&](int ck) {
@@ -165,6 +169,8 @@ FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
       }
     }
   }
+  if (!best.ok && phaseX == 3)                            // no 48-cout tiling fits: ordinary tiles, scalar phase stores
+    return plan_fwd(B, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, allow_split, phase, 1);
   return best;
 }
 
@@ -616,6 +622,45 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
     }
     return;
   }
+  if constexpr (PH && NB == 3) {
+    // stride-(1,3) backward-data with 48-cout tiles: cout' = 3*channel + phase.  All three tiles of a pixel block go
+    // through a wave-private LDS patch; a lane then owns (channel, 4 pixels) = 12 consecutive floats of dx and writes
+    // them as three 16-byte stores (the scalar path scatters 4-byte stores 12 bytes apart).
+    if (!split && p.outXmul == 3 && p.outYmul == 1 && (p.TW & 3) == 0 && (p.OW & 3) == 0 && ((p.outRS * 3) & 3) == 0) {
+      __syncthreads();
+      float* patch = lds + wave * (48 * 20);           // [cout' 48][pixel 16 (+4 pad)]
+      const int cc_l = lane >> 2, quad = lane & 3;
+      const int cc = cot * 16 + cc_l;                  // channel of dx
+      float* yb = p.y + (long)b * p.outBS + (long)cc * p.outCS;
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        const int pix4 = (wave * PB + pb) * 16 + quad * 4;
+        const int pc = pix4 < npix ? pix4 : 0;
+        const int py = pc / p.TW, px = pc - py * p.TW;
+        const int oy = oy0 + py, ox = ox0 + px;
+        const bool ok4 = pix4 < npix && oy < p.OH && ox < p.OW && cc < p.outCdiv;
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) patch[(nb * 16 + kq * 4 + r) * 20 + l16] = acc[nb][pb][r];
+        __builtin_amdgcn_wave_barrier();
+        float o[12];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const float4 t = *reinterpret_cast<const float4*>(patch + (cc_l * 3 + q) * 20 + quad * 4);
+          o[q] = t.x; o[3 + q] = t.y; o[6 + q] = t.z; o[9 + q] = t.w;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (ok4) {
+          float* dst = yb + (long)oy * p.outRS + (long)ox * 3;
+          *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+          *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+          *reinterpret_cast<float4*>(dst + 8) = make_float4(o[8], o[9], o[10], o[11]);
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int pb = 0; pb < PB; ++pb) {
     const int pix = (wave * PB + pb) * 16 + l16;
@@ -707,8 +752,20 @@ int launch_fwd_nb(const FwdPlan& pl, const ConvFwdParams& p, hipStream_t s) {
   }
 }
 
+int launch_fwd_nb3(const FwdPlan& pl, const ConvFwdParams& p, hipStream_t s) {      // phase-store builds only
+  dim3 grid((unsigned)(mpa_cdiv(p.nTilesAll, 8) * 8 * pl.coTiles), 1, (unsigned)mpa_cdiv(pl.nChunks, p.chunksPer));
+  if (pl.KWS != 0 || p.outCdiv >= p.Cout) return MPA_ERR_UNSUPPORTED;
+  switch (pl.PB) {
+    case 4: return launch_fwd_ef<3, 4, 0, false, true>(pl, p, grid, s);
+    case 6: return launch_fwd_ef<3, 6, 0, false, true>(pl, p, grid, s);
+    case 8: return launch_fwd_ef<3, 8, 0, false, true>(pl, p, grid, s);
+    default: return MPA_ERR_UNSUPPORTED;
+  }
+}
+
 int launch_fwd(const FwdPlan& pl, const ConvFwdParams& p, hipStream_t s) {
   switch (pl.NB) {
+    case 3: return launch_fwd_nb3(pl, p, s);
     case 1: return launch_fwd_nb<1>(pl, p, s);
     case 2: return launch_fwd_nb<2>(pl, p, s);
     case 4: return launch_fwd_nb<4>(pl, p, s);
@@ -812,7 +869,8 @@ BwdDataGeom bwd_data_geom(const mpa_conv_desc* d) {
 }
 
 inline FwdPlan plan_bwd_data(const mpa_conv_desc* d, const BwdDataGeom& g) {
-  return plan_fwd(d->B, g.Cin, g.Hplan, g.W, g.Cout, g.kh, g.kw, g.sh, 1, g.ph, g.pw, true, g.xphase || g.yphase > 1);
+  return plan_fwd(d->B, g.Cin, g.Hplan, g.W, g.Cout, g.kh, g.kw, g.sh, 1, g.ph, g.pw, true, g.xphase || g.yphase > 1,
+                  g.xphase ? d->sw : 1);
 }
 
 // ------------------------------------------------------------------------------------------------ backward-weight
@@ -1312,7 +1370,8 @@ static int conv_fwd_impl(int B, int Cin, int H, int W, int Cout, int kh, int kw,
                          const float* x, const float* wp, const float* bias, float* y, int act, float slope,
                          long outBS, long outCS, int outRS, int outXmul, int outCdiv, hipStream_t s, bool allow_split = false,
                          int Hplan = 0, int outYmul = 1, int outH = 0) {
-  FwdPlan pl = plan_fwd(B, Cin, Hplan ? Hplan : H, W, Cout, kh, kw, sh, sw, ph, pw, allow_split, outCdiv < Cout);
+  FwdPlan pl = plan_fwd(B, Cin, Hplan ? Hplan : H, W, Cout, kh, kw, sh, sw, ph, pw, allow_split, outCdiv < Cout,
+                        outCdiv < Cout ? outXmul : 1);
   if (!pl.ok) return MPA_ERR_UNSUPPORTED;
   ConvFwdParams p{};
   p.x = x; p.wp = wp; p.bias = bias; p.y = y;
