@@ -1122,6 +1122,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgParams p) {
 //   wave tile: NBC cout blocks x CIW input channels x 15 dy  (acc = NBC*CIW*15 tiles of 16x16)
 //   block    : 4 waves = 4*CIW input channels sharing one dY tile of NBC*16 couts
 constexpr int W15_PITCH = 128;
+constexpr int W15G_DEPTH = 2;      // dY-from-global variant: groups of 16 pixels whose dY quads are in flight
 
 struct Wg15Params {
   const float* x;
@@ -1130,7 +1131,7 @@ struct Wg15Params {
   int B, Cin, H, W, Cout, OH, OW;
   int COT, TH, TW, DP, tilesY, tilesX, IH, IW, DCP, S, Ntot, TX64, TD64;
   int quad;  // 16-byte LDS-DMA staging (aligned geometry): the X window then starts one column further left (ox0-8)
-  int dbg;   // diagnostics (env MPA_DEBUG_WG15): 1 = stage only the first tile, 2 = skip the MFMA loop
+  int dbg;   // diagnostics (env MPA_DEBUG_WG15): 1 = stage only the first tile, 2 = skip the MFMA loop, 3 = 1 + no barriers
 };
 
 template <int NBC, int CIW>
@@ -1143,6 +1144,9 @@ __global__ __launch_bounds__(256) void conv_wgrad15_kernel(const Wg15Params p) {
   const int split = blockIdx.x, cig = blockIdx.y, cot = blockIdx.z;
   const int ci_first = cig * 4 * CIW;
   const int xchp = p.IH * W15_PITCH;
+  // Two workgroups share a CU and start in lock-step, so they would stage (and idle the MFMA pipe) together forever.
+  // The one whose LDS allocation does not start at 0 gets issue priority: it runs at full speed, the other fills the
+  // gaps and the first one's staging time -- and each one's staging now falls into the other's compute phase.
   const int NtotP = p.Ntot + 1;
   const bool do_bias = cig == 0;
   float bsum = 0.f;
@@ -1163,8 +1167,8 @@ __global__ __launch_bounds__(256) void conv_wgrad15_kernel(const Wg15Params p) {
     const int tr = (int)(tile - (long)b * tilesPerImg);
     const int ty = tr / p.tilesX, tx = tr - ty * p.tilesX;
     const int oy0 = ty * p.TH, ox0 = tx * p.TW;
-    __syncthreads();
-    if (p.dbg != 1 || tile == split) {
+    if (p.dbg != 3) __syncthreads();
+    if ((p.dbg != 1 && p.dbg != 3) || tile == split) {
       if (p.quad) {
         glds_stage_x16(lds_x, p.x + (long)b * p.Cin * p.H * p.W, lane, wave, 4 * CIW, p.IH, W15_PITCH, xchp, p.TX64,
                        ci_first, oy0 - 7, ox0 - 8, p.Cin, p.H, p.W);
@@ -1178,7 +1182,7 @@ __global__ __launch_bounds__(256) void conv_wgrad15_kernel(const Wg15Params p) {
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (p.dbg != 3 || tile == split) __syncthreads();
     if (p.dbg == 2) continue;
     if (do_bias) {
       const int co = tid >> 1, part = tid & 1;
@@ -1252,8 +1256,189 @@ __global__ __launch_bounds__(256) void conv_wgrad15_kernel(const Wg15Params p) {
   }
 }
 
+// Variant with the dY operand read straight from global memory (quad geometry: OW % 4 == 0, tile origins % 4 == 0).
+// Staging dY through LDS costs time in proportion to its bytes that nothing hides (measured: 42 KB dY + 35 KB X per
+// 3x108 tile = 7 % of the kernel, whatever the mechanism -- LDS-DMA or registers -- and whatever the phase between the
+// two co-resident workgroups).  Here a lane loads one float4 = 4 consecutive pixels of its cout row and uses it as the A
+// operand of 4 consecutive k-steps: k-step j of a 16-pixel group contracts pixels {16g + 4kq + j}, so the B operand
+// sits at `4kq + dx + (16g + j)` -- still base + immediate.  The next group's float4 is in flight during the current
+// group's 120 MFMAs.  LDS then holds the X tile only, which buys TH up to 25 rows (halo overhead 1.6x instead of 5.7x).
+// A row's last DP % 16 pixels are a tail of 1-3 ordinary k-steps (pixels {4s + kq}, dword loads).
+template <int NBC, bool TAIL>
+__global__ __launch_bounds__(256, 2) void conv_wgrad15g_kernel(const Wg15Params p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* lds_x = lds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kq = lane >> 4, l16 = lane & 15;
+  const int split = blockIdx.x, cig = blockIdx.y, cot = blockIdx.z;
+  const int ci_first = cig * 4;
+  const int xchp = p.IH * W15_PITCH;
+  const int NtotP = p.Ntot + 1;
+  const bool do_bias = cig == 0 && wave == 0;
+  float bs[NBC];
+  f32x4 acc[NBC][15];
+#pragma unroll
+  for (int a = 0; a < NBC; ++a) {
+    bs[a] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 15; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int tilesPerImg = p.tilesY * p.tilesX;
+  const long totalTiles = (long)p.B * tilesPerImg;
+  const int nfull = p.DP >> 4, tail = (p.DP & 15) >> 2;     // nfull >= 1; TAIL == (tail != 0)
+  const float* bfull = lds_x + wave * xchp + 4 * kq + l16 + 1;
+  const float* btail = lds_x + wave * xchp + kq + l16 + 1 + 16 * nfull;
+  const int plane = p.OH * p.OW;
+  bool co_ok[NBC];
+#pragma unroll
+  for (int cb = 0; cb < NBC; ++cb) co_ok[cb] = cot * p.COT + cb * 16 + l16 < p.Cout;
+
+  for (long tile = split; tile < totalTiles; tile += p.S) {
+    const int b = (int)(tile / tilesPerImg);
+    const int tr = (int)(tile - (long)b * tilesPerImg);
+    const int ty = tr / p.tilesX, tx = tr - ty * p.tilesX;
+    const int oy0 = ty * p.TH, ox0 = tx * p.TW;
+    const int xlim = min(p.OW, ox0 + p.TW);
+    // this lane's cout row of dY, at the tile origin
+    const float* dyl = p.dy + ((long)b * p.Cout + cot * p.COT + l16) * plane + (long)oy0 * p.OW + ox0;
+    auto load_full = [&](float4* a, int py, int g) {
+      const int px = 16 * g + 4 * kq;
+      const bool ok = oy0 + py < p.OH && ox0 + px + 3 < xlim;
+#pragma unroll
+      for (int cb = 0; cb < NBC; ++cb)
+        a[cb] = (ok && co_ok[cb]) ? *reinterpret_cast<const float4*>(dyl + (long)cb * 16 * plane + py * p.OW + px)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    __syncthreads();
+    if (p.dbg != 1 || tile == split)
+      glds_stage_x16(lds_x, p.x + (long)b * p.Cin * p.H * p.W, lane, wave, 4, p.IH, W15_PITCH, xchp, p.TX64, ci_first,
+                     oy0 - 7, ox0 - 8, p.Cin, p.H, p.W);
+    float4 an[W15G_DEPTH][NBC];       // dY quads of the next W15G_DEPTH groups, in flight
+#pragma unroll
+    for (int d = 0; d < W15G_DEPTH; ++d) load_full(an[d], d / nfull, d % nfull);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (p.dbg == 2) continue;
+
+    float b0[15], b1[15];
+#define W15G_LOAD(Bv, BP, IMM)                                                              \
+  { _Pragma("unroll") for (int t = 0; t < 15; ++t) Bv[t] = (BP)[t * W15_PITCH + (IMM)]; }
+#define W15G_MMA(AV, AC, Bv)                                                                \
+  {                                                                                         \
+    _Pragma("unroll") for (int t = 0; t < 15; ++t)                                          \
+      _Pragma("unroll") for (int cb = 0; cb < NBC; ++cb)                                    \
+        acc[cb][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[cb].AC, Bv[t], acc[cb][t], 0, 0, 0); \
+  }
+    const float* bp = bfull;
+    W15G_LOAD(b0, bp, 0)
+    for (int py = 0; py < p.TH; ++py) {
+      float4 at[NBC];
+      if constexpr (TAIL) {     // the row's last 4..12 pixels: k-step s contracts pixels {16 nfull + 4s + kq}
+        const int px = 16 * nfull + kq;
+        const bool rowok = oy0 + py < p.OH;
+#pragma unroll
+        for (int cb = 0; cb < NBC; ++cb) {
+          const float* src = dyl + (long)cb * 16 * plane + py * p.OW + px;
+          const bool ok = rowok && co_ok[cb];
+          at[cb].x = (ok && ox0 + px < xlim) ? src[0] : 0.f;
+          at[cb].y = (ok && tail > 1 && ox0 + px + 4 < xlim) ? src[4] : 0.f;
+          at[cb].z = (ok && tail > 2 && ox0 + px + 8 < xlim) ? src[8] : 0.f;
+          at[cb].w = 0.f;
+        }
+      }
+      for (int g = 0; g < nfull; ++g) {
+        float4 ac[NBC];
+#pragma unroll
+        for (int cb = 0; cb < NBC; ++cb) {
+          ac[cb] = an[0][cb];
+#pragma unroll
+          for (int d = 0; d + 1 < W15G_DEPTH; ++d) an[d][cb] = an[d + 1][cb];
+        }
+        const bool last = g + 1 == nfull;
+        const int npy = last ? py + 1 : py;
+        {
+          const int gd = g + W15G_DEPTH, pyd = py + gd / nfull;
+          if (pyd < p.TH) load_full(an[W15G_DEPTH - 1], pyd, gd % nfull);
+        }
+        const float* bpn = last ? (TAIL ? btail + py * W15_PITCH : bfull + npy * W15_PITCH) : bp + 16;
+        if (do_bias) {
+#pragma unroll
+          for (int cb = 0; cb < NBC; ++cb) bs[cb] += (ac[cb].x + ac[cb].y) + (ac[cb].z + ac[cb].w);
+        }
+        W15G_LOAD(b1, bp, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        W15G_MMA(ac, x, b0)
+        __builtin_amdgcn_sched_barrier(0);
+        W15G_LOAD(b0, bp, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        W15G_MMA(ac, y, b1)
+        __builtin_amdgcn_sched_barrier(0);
+        W15G_LOAD(b1, bp, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        W15G_MMA(ac, z, b0)
+        __builtin_amdgcn_sched_barrier(0);
+        W15G_LOAD(b0, bpn, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        W15G_MMA(ac, w, b1)
+        __builtin_amdgcn_sched_barrier(0);
+        bp = bpn;
+      }
+      if constexpr (TAIL) {
+        // always three k-steps: those past `tail` have A == 0 (the planner prefers DP % 16 in {0, 12})
+        const float* bpn = bfull + (py + 1) * W15_PITCH;
+        if (do_bias) {
+#pragma unroll
+          for (int cb = 0; cb < NBC; ++cb) bs[cb] += (at[cb].x + at[cb].y) + at[cb].z;
+        }
+        W15G_LOAD(b1, bp, 4)
+        __builtin_amdgcn_sched_barrier(0);
+        W15G_MMA(at, x, b0)
+        __builtin_amdgcn_sched_barrier(0);
+        W15G_LOAD(b0, bp, 8)
+        __builtin_amdgcn_sched_barrier(0);
+        W15G_MMA(at, y, b1)
+        __builtin_amdgcn_sched_barrier(0);
+        W15G_LOAD(b1, bpn, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        W15G_MMA(at, z, b0)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 15; ++t) b0[t] = b1[t];
+        bp = bpn;
+      }
+    }
+#undef W15G_LOAD
+#undef W15G_MMA
+  }
+  // D[row = cout (kq*4+r)][col = dx (l16)]
+  float* out = p.ws + (long)split * p.Cout * NtotP;
+  const int ci = ci_first + wave;
+  if (l16 < 15 && ci < p.Cin) {
+#pragma unroll
+    for (int t = 0; t < 15; ++t)
+#pragma unroll
+      for (int cb = 0; cb < NBC; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = cot * p.COT + cb * 16 + kq * 4 + r;
+          if (co < p.Cout) out[(long)co * NtotP + ci * 225 + t * 15 + l16] = acc[cb][t][r];
+        }
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int cb = 0; cb < NBC; ++cb) {
+      float v = bs[cb];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int co = cot * p.COT + cb * 16 + l16;
+      if (kq == 0 && co < p.Cout) out[(long)co * NtotP + p.Ntot] = v;
+    }
+  }
+}
+
 struct Wg15Plan {
   int NBC, CIW, COT, coTiles, ciGroups, TH, TW, DP, tilesY, tilesX, IH, IW, DCP, S, TX64, TD64, quad;
+  int ga;    // conv_wgrad15g_kernel: dY operand from global memory, LDS holds the X tile only
   size_t lds_bytes;
   bool ok;
 };
@@ -1270,7 +1455,29 @@ Wg15Plan plan_wgrad15(const mpa_conv_desc* d) {
   pl.ciGroups = (int)mpa_cdiv(d->Cin, 4 * pl.CIW);
   const long budget = 78 * 1024;      // two workgroups per CU (160 KiB LDS)
   double bestcost = 1e300;
-  for (int txn = 1; txn <= OW; ++txn) {
+  // dY-from-global variant: whole-width quads, at most 7 groups of 16 pixels per row (X pitch 128)
+  if (OW % 4 == 0 && !getenv("MPA_WG15_LDS_DY")) {
+    for (int txn = 1; txn <= 8; ++txn) {
+      const int TW = (int)mpa_cdiv(mpa_cdiv(OW, txn), 4) * 4;
+      if (TW > 112 || TW < 16 || (long)TW * (txn - 1) >= OW) continue;
+      for (int TH = std::min(OH, 25); TH >= 1; --TH) {
+        const int IH = TH + 14;
+        const long tx64 = (long)4 * IH * W15_PITCH;
+        if (tx64 * 4 > budget) continue;
+        const int ty = (int)mpa_cdiv(OH, TH);
+        const double mfma = (double)TH * (TW / 4) * pl.NBC * 15 * 32.0;
+        const double stage = (double)tx64 / 64.0 * 80.0 / 4.0;
+        const double cost = (double)ty * txn * (mfma + stage + 3000.0);
+        if (cost < bestcost) {
+          bestcost = cost;
+          pl.TH = TH; pl.TW = TW; pl.DP = TW; pl.tilesY = ty; pl.tilesX = txn; pl.IH = IH; pl.IW = W15_PITCH; pl.DCP = 0;
+          pl.quad = 1; pl.ga = 1;
+          pl.TX64 = (int)tx64; pl.TD64 = 0; pl.lds_bytes = (size_t)tx64 * 4; pl.ok = true;
+        }
+      }
+    }
+  }
+  for (int txn = 1; txn <= OW && !pl.ga; ++txn) {
     const int TW = (int)mpa_cdiv(OW, txn);
     const int DP = (int)mpa_cdiv(TW, 4) * 4;
     // 16-byte LDS-DMA needs every tile origin and the tensor width 4-aligned; the X window then spans DP+15 columns
@@ -1432,8 +1639,8 @@ int mpa_conv2d_describe_plan(const mpa_conv_desc* d, int mode, char* buf, int bu
   if (mode == 2) {
     Wg15Plan q = plan_wgrad15(d);
     if (q.ok) {
-      snprintf(buf, buflen, "wgrad15<%d,%d> COT=%d coTiles=%d ciGroups=%d tile=%dx%d (DP %d) tiles=%dx%d S=%d lds=%zuB", q.NBC,
-               q.CIW, q.COT, q.coTiles, q.ciGroups, q.TH, q.TW, q.DP, q.tilesY, q.tilesX, q.S, q.lds_bytes);
+      snprintf(buf, buflen, "wgrad15%s<%d,%d> COT=%d coTiles=%d ciGroups=%d tile=%dx%d (DP %d) tiles=%dx%d S=%d lds=%zuB",
+               q.ga ? "g" : "", q.NBC, q.CIW, q.COT, q.coTiles, q.ciGroups, q.TH, q.TW, q.DP, q.tilesY, q.tilesX, q.S, q.lds_bytes);
       return MPA_OK;
     }
     WgPlan w = plan_wgrad(d);
@@ -1487,6 +1694,21 @@ int mpa_conv2d_bwd_weight(const mpa_conv_desc* d, const float* x, const float* d
       (void)hipFuncSetAttribute((const void*)conv_wgrad15_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
       attr_set = true;
     }
+    if (p15.ga) {
+      static bool attr_g = false;
+      if (!attr_g) {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad15g_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad15g_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad15g_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad15g_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr_g = true;
+      }
+      const bool tl = (p15.DP & 15) != 0;
+      if (p15.NBC == 1 && !tl) MPA_LAUNCH((conv_wgrad15g_kernel<1, false>), grid15, dim3(256), p15.lds_bytes, s15, q);
+      else if (p15.NBC == 1) MPA_LAUNCH((conv_wgrad15g_kernel<1, true>), grid15, dim3(256), p15.lds_bytes, s15, q);
+      else if (!tl) MPA_LAUNCH((conv_wgrad15g_kernel<2, false>), grid15, dim3(256), p15.lds_bytes, s15, q);
+      else MPA_LAUNCH((conv_wgrad15g_kernel<2, true>), grid15, dim3(256), p15.lds_bytes, s15, q);
+    } else
     if (p15.NBC == 1) MPA_LAUNCH((conv_wgrad15_kernel<1, 1>), grid15, dim3(256), p15.lds_bytes, s15, q);
     else MPA_LAUNCH((conv_wgrad15_kernel<2, 1>), grid15, dim3(256), p15.lds_bytes, s15, q);
     int rc15 = mpa_launch_status();
