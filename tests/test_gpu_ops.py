@@ -420,3 +420,42 @@ def test_conv2d_random_shapes(dev, case):
         _close(xg.grad, xr.grad, 2e-5, "dx")
     _close(wg.grad, wr.grad, 5e-5, "dw")
     _close(bg.grad, br.grad, 5e-5, "db")
+
+
+# 15x15 stride-1 'same' convolutions have their own backward-weight kernels: widths % 4 == 0 take the dY-from-global
+# variant (16-pixel groups + a tail of 0..3 k-steps, up to 7 groups, tiles up to 25 rows), other widths the LDS-staged
+# one.  Every (groups, tail) combination, Cout not a multiple of 16 / 32, Cin not a multiple of 4, H < / > / = tile height.
+WG15_CASES = [
+    # B, Cin, H, W, Cout
+    (2, 4, 9, 16, 16),      # one group, no tail
+    (2, 3, 5, 20, 7),       # one group + tail 1, ragged couts/cins
+    (3, 6, 26, 24, 16),     # tail 2, H just over one 25-row tile
+    (2, 5, 25, 28, 33),     # tail 3, NBC = 2 with a ragged third cout tile
+    (1, 8, 40, 108, 32),    # the model's half-width rows: 6 groups + tail 3
+    (2, 2, 7, 112, 20),     # 7 full groups (the widest tile)
+    (2, 6, 12, 216, 16),    # two tiles of 108 per row
+    (1, 4, 30, 120, 48),    # two tiles of 60: 3 groups + tail 3
+    (2, 4, 11, 12, 16),     # width < 16: falls back to the LDS-staged kernel
+    (2, 4, 11, 54, 24),     # width % 4 != 0: LDS-staged kernel
+    (5, 16, 3, 36, 128),    # H < 15, many couts
+]
+
+
+@pytest.mark.parametrize("case", WG15_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv15_backward_weight_variants(dev, case):
+    from multipitch_architectures_amd import ops
+    B, Cin, H, W, Cout = case
+    x = _rand((B, Cin, H, W), 21)
+    w = _rand((Cout, Cin, 15, 15), 22, (2.0 / (Cin * 225)) ** 0.5)
+    b = _rand((Cout,), 23, 0.1)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv2d(xr, wr, br, padding=7)
+    gy = _rand(tuple(yr.shape), 24)
+    yr.backward(gy.double())
+    xg, wg, bg = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    y = ops.conv2d(xg, wg, bg, (1, 1), (7, 7), ops.ACT_NONE, 0.0)
+    y.backward(gy.to(dev))
+    _close(y, yr, 2e-5, "y")
+    _close(xg.grad, xr.grad, 2e-5, "dx")
+    _close(wg.grad, wr.grad, 5e-5, "dw")
+    _close(bg.grad, br.grad, 5e-5, "db")
