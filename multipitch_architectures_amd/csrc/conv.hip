@@ -1264,7 +1264,9 @@ __global__ __launch_bounds__(256) void conv_wgrad15_kernel(const Wg15Params p) {
 // sits at `4kq + dx + (16g + j)` -- still base + immediate.  The next group's float4 is in flight during the current
 // group's 120 MFMAs.  LDS then holds the X tile only, which buys TH up to 25 rows (halo overhead 1.6x instead of 5.7x).
 // A row's last DP % 16 pixels are a tail of 1-3 ordinary k-steps (pixels {4s + kq}, dword loads).
-template <int NBC, bool TAIL>
+// EVEN: the number of full groups per row is even, the group loop runs two groups per trip and the rotation of the
+// W15G_DEPTH = 2 in-flight dY register sets is register renaming instead of 16 v_mov per group.
+template <int NBC, bool TAIL, bool EVEN = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad15g_kernel(const Wg15Params p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lds_x = lds;
@@ -1289,25 +1291,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad15g_kernel(const Wg15Params 
   const float* bfull = lds_x + wave * xchp + 4 * kq + l16 + 1;
   const float* btail = lds_x + wave * xchp + kq + l16 + 1 + 16 * nfull;
   const int plane = p.OH * p.OW;
-  bool co_ok[NBC];
-#pragma unroll
-  for (int cb = 0; cb < NBC; ++cb) co_ok[cb] = cot * p.COT + cb * 16 + l16 < p.Cout;
+  const int loff = (l16 * plane + 4 * kq) * 4, loff_t = (l16 * plane + kq) * 4;     // bytes
 
   for (long tile = split; tile < totalTiles; tile += p.S) {
     const int b = (int)(tile / tilesPerImg);
     const int tr = (int)(tile - (long)b * tilesPerImg);
     const int ty = tr / p.tilesX, tx = tr - ty * p.tilesX;
     const int oy0 = ty * p.TH, ox0 = tx * p.TW;
-    const int xlim = min(p.OW, ox0 + p.TW);
-    // this lane's cout row of dY, at the tile origin
-    const float* dyl = p.dy + ((long)b * p.Cout + cot * p.COT + l16) * plane + (long)oy0 * p.OW + ox0;
+    // dY quads by buffer loads: the wave-uniform part of the address (cout block, row, group) goes into the resource's
+    // base and num_records on the scalar unit, the lane part (cout row l16, quad kq) is one VGPR for the whole kernel,
+    // and whatever falls outside the image's dY -- couts past Cout, rows past OH (num_records = 0) -- reads as zero
+    // without a single vector instruction.  Tiles are exact in x (planner), so there is no per-lane column test.
+    const float* imgb = p.dy + (long)b * p.Cout * plane;
+    const int img_elems = p.Cout * plane;
+    auto dy_rsrc = [&](int cb, int py, int col, bool on) {
+      const int u = (cot * p.COT + cb * 16) * plane + (oy0 + py) * p.OW + ox0 + col;
+      const int left = (on && oy0 + py < p.OH && u < img_elems) ? (img_elems - u) * 4 : 0;
+      return __builtin_amdgcn_make_buffer_rsrc((void*)(imgb + u), 0, left, 0x00020000);
+    };
     auto load_full = [&](float4* a, int py, int g) {
-      const int px = 16 * g + 4 * kq;
-      const bool ok = oy0 + py < p.OH && ox0 + px + 3 < xlim;
 #pragma unroll
       for (int cb = 0; cb < NBC; ++cb)
-        a[cb] = (ok && co_ok[cb]) ? *reinterpret_cast<const float4*>(dyl + (long)cb * 16 * plane + py * p.OW + px)
-                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+        a[cb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(dy_rsrc(cb, py, 16 * g, true), loff, 0, 0));
     };
     __syncthreads();
     if (p.dbg != 1 || tile == split)
@@ -1334,19 +1339,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad15g_kernel(const Wg15Params 
     for (int py = 0; py < p.TH; ++py) {
       float4 at[NBC];
       if constexpr (TAIL) {     // the row's last 4..12 pixels: k-step s contracts pixels {16 nfull + 4s + kq}
-        const int px = 16 * nfull + kq;
-        const bool rowok = oy0 + py < p.OH;
 #pragma unroll
         for (int cb = 0; cb < NBC; ++cb) {
-          const float* src = dyl + (long)cb * 16 * plane + py * p.OW + px;
-          const bool ok = rowok && co_ok[cb];
-          at[cb].x = (ok && ox0 + px < xlim) ? src[0] : 0.f;
-          at[cb].y = (ok && tail > 1 && ox0 + px + 4 < xlim) ? src[4] : 0.f;
-          at[cb].z = (ok && tail > 2 && ox0 + px + 8 < xlim) ? src[8] : 0.f;
+          at[cb].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc(cb, py, 16 * nfull, true), loff_t, 0, 0));
+          at[cb].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc(cb, py, 16 * nfull + 4, tail > 1), loff_t, 0, 0));
+          at[cb].z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc(cb, py, 16 * nfull + 8, tail > 2), loff_t, 0, 0));
           at[cb].w = 0.f;
         }
       }
-      for (int g = 0; g < nfull; ++g) {
+      auto group = [&](const int g) {
         float4 ac[NBC];
 #pragma unroll
         for (int cb = 0; cb < NBC; ++cb) {
@@ -1357,8 +1358,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad15g_kernel(const Wg15Params 
         const bool last = g + 1 == nfull;
         const int npy = last ? py + 1 : py;
         {
-          const int gd = g + W15G_DEPTH, pyd = py + gd / nfull;
-          if (pyd < p.TH) load_full(an[W15G_DEPTH - 1], pyd, gd % nfull);
+          int gd = g + W15G_DEPTH, pyd = py;
+          while (gd >= nfull) { gd -= nfull; ++pyd; }
+          if (pyd < p.TH) load_full(an[W15G_DEPTH - 1], pyd, gd);
         }
         const float* bpn = last ? (TAIL ? btail + py * W15_PITCH : bfull + npy * W15_PITCH) : bp + 16;
         if (do_bias) {
@@ -1382,6 +1384,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad15g_kernel(const Wg15Params 
         W15G_MMA(ac, w, b1)
         __builtin_amdgcn_sched_barrier(0);
         bp = bpn;
+      };
+      if constexpr (EVEN) {
+        static_assert(W15G_DEPTH == 2, "the two-groups-per-trip loop renames exactly two in-flight sets");
+        for (int g = 0; g < nfull; g += 2) { group(g); group(g + 1); }
+      } else {
+        for (int g = 0; g < nfull; ++g) group(g);
       }
       if constexpr (TAIL) {
         // always three k-steps: those past `tail` have A == 0 (the planner prefers DP % 16 in {0, 12})
@@ -1459,7 +1467,7 @@ Wg15Plan plan_wgrad15(const mpa_conv_desc* d) {
   if (OW % 4 == 0 && !getenv("MPA_WG15_LDS_DY")) {
     for (int txn = 1; txn <= 8; ++txn) {
       const int TW = (int)mpa_cdiv(mpa_cdiv(OW, txn), 4) * 4;
-      if (TW > 112 || TW < 16 || (long)TW * (txn - 1) >= OW) continue;
+      if (TW > 112 || TW < 16 || (long)TW * txn != OW) continue;      // exact tiling: no per-lane column bounds
       for (int TH = std::min(OH, 25); TH >= 1; --TH) {
         const int IH = TH + 14;
         const long tx64 = (long)4 * IH * W15_PITCH;
@@ -1697,17 +1705,23 @@ int mpa_conv2d_bwd_weight(const mpa_conv_desc* d, const float* x, const float* d
     if (p15.ga) {
       static bool attr_g = false;
       if (!attr_g) {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad15g_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_wgrad15g_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_wgrad15g_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_wgrad15g_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+#define MPA_WG15G_ATTR(...) (void)hipFuncSetAttribute((const void*)conv_wgrad15g_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)
+        MPA_WG15G_ATTR(1, false); MPA_WG15G_ATTR(2, false); MPA_WG15G_ATTR(1, true); MPA_WG15G_ATTR(2, true);
+        MPA_WG15G_ATTR(1, false, true); MPA_WG15G_ATTR(2, false, true); MPA_WG15G_ATTR(1, true, true); MPA_WG15G_ATTR(2, true, true);
+#undef MPA_WG15G_ATTR
         attr_g = true;
       }
       const bool tl = (p15.DP & 15) != 0;
-      if (p15.NBC == 1 && !tl) MPA_LAUNCH((conv_wgrad15g_kernel<1, false>), grid15, dim3(256), p15.lds_bytes, s15, q);
-      else if (p15.NBC == 1) MPA_LAUNCH((conv_wgrad15g_kernel<1, true>), grid15, dim3(256), p15.lds_bytes, s15, q);
-      else if (!tl) MPA_LAUNCH((conv_wgrad15g_kernel<2, false>), grid15, dim3(256), p15.lds_bytes, s15, q);
-      else MPA_LAUNCH((conv_wgrad15g_kernel<2, true>), grid15, dim3(256), p15.lds_bytes, s15, q);
+      const bool ev = ((p15.DP >> 4) & 1) == 0 && !getenv("MPA_WG15_NOUNROLL");
+#define MPA_WG15G_GO(...) MPA_LAUNCH((conv_wgrad15g_kernel<__VA_ARGS__>), grid15, dim3(256), p15.lds_bytes, s15, q)
+      if (p15.NBC == 1) {
+        if (tl) { if (ev) MPA_WG15G_GO(1, true, true); else MPA_WG15G_GO(1, true, false); }
+        else { if (ev) MPA_WG15G_GO(1, false, true); else MPA_WG15G_GO(1, false, false); }
+      } else {
+        if (tl) { if (ev) MPA_WG15G_GO(2, true, true); else MPA_WG15G_GO(2, true, false); }
+        else { if (ev) MPA_WG15G_GO(2, false, true); else MPA_WG15G_GO(2, false, false); }
+      }
+#undef MPA_WG15G_GO
     } else
     if (p15.NBC == 1) MPA_LAUNCH((conv_wgrad15_kernel<1, 1>), grid15, dim3(256), p15.lds_bytes, s15, q);
     else MPA_LAUNCH((conv_wgrad15_kernel<2, 1>), grid15, dim3(256), p15.lds_bytes, s15, q);
