@@ -874,12 +874,16 @@ inline FwdPlan plan_bwd_data(const mpa_conv_desc* d, const BwdDataGeom& g) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward-weight
+constexpr int WGG_DEPTH = 2;      // conv_wgrad_g_kernel: 16-pixel groups whose dY quads are in flight
+constexpr int WGG_SLACK = 64;      // ... and zeroed LDS words behind its X tile
+
 struct WgPlan {
   int NBC, NTW, COT, coTiles, nPerBlock, nTiles, Ntot, XCH, TH, TW, DP, tilesY, tilesX, IH, IW, LW, XCHP, DCP, S, OH, OW;
   size_t lds_bytes;
   bool ok;
   int quad, xshift;   // 16-byte LDS-DMA staging: 4-aligned window origin (x0a = ix0 - xshift), pitches % 4 == 0
   int ef;             // row ends are not quad aligned: edge_fix_* completes the straddling quads
+  int ga;             // conv_wgrad_g_kernel: dY operand from global memory, LDS holds the X tile only
 };
 
 WgPlan plan_wgrad(const mpa_conv_desc* d) {
@@ -903,6 +907,41 @@ WgPlan plan_wgrad(const mpa_conv_desc* d) {
     pl.XCH = std::min(d->Cin, (pl.nPerBlock + khkw - 2) / khkw + 1);
     const double pad_eff = ((double)pl.coTiles * pl.COT / d->Cout) * ((double)pl.nTiles * pl.nPerBlock / Ntot);
     static const int force_txn = getenv("MPA_WG_TXN") ? atoi(getenv("MPA_WG_TXN")) : 0;   // diagnostics
+    // dY-from-global variant: exact tiling of 4-aligned rows, stride 1 (any variant) or the head's stride 3 (<5,6>)
+    static const bool no_ga = getenv("MPA_WG_NOGA") != nullptr;
+    const bool ga_sw = d->sw == 1 || (d->sw == 3 && pl.NBC == 5);
+    if (!no_ga && !force_txn && ga_sw && (OW & 3) == 0 && (d->W & 3) == 0) {
+      for (int txn = 1; txn <= 16; ++txn) {
+        if (OW % txn) continue;
+        const int TW = OW / txn;
+        if ((TW & 3) || TW < 16) continue;
+        const int IW = (TW - 1) * d->sw + d->kw;
+        const int xshift = ((-d->pw) % 4 + 4) % 4;
+        const int LW = (int)mpa_cdiv(IW + 3, 4) * 4;
+        for (int THmax = std::min(OH, 64); THmax >= 1; --THmax) {
+          if ((mpa_cdiv((long)pl.XCH * ((THmax - 1) * d->sh + d->kh) * LW, 64) * 64 + WGG_SLACK) * 4 > 64 * 1024) continue;
+          const int ty = (int)mpa_cdiv(OH, THmax);
+          const int TH = (int)mpa_cdiv(OH, ty);        // the largest tile that fits, then balanced over the rows
+          const int IH = (TH - 1) * d->sh + d->kh;
+          const int XCHP = IH * LW;
+          const long floats = mpa_cdiv((long)pl.XCH * XCHP, 64) * 64 + WGG_SLACK;
+          const int ksteps = (TW >> 4) * 4 + ((TW & 15) ? 3 : 0);
+          // per k-step: the MFMAs + one B read per tap block (+ its address add once per group); dY costs nothing here
+          const double mfma = (double)TH * (ksteps * (pl.NBC * pl.NTW * 32.0 + 5.0 * pl.NTW) + 120.0);
+          const double words = (double)pl.XCH * IH * LW;
+          const double stage = words / 256.0 * 80.0;
+          const double cost = (double)ty * txn * (mfma + 0.7 * stage + 600.0) * pad_eff;
+          if (cost < bestcost) {
+            bestcost = cost;
+            best = pl;
+            best.TH = TH; best.TW = TW; best.DP = TW; best.tilesY = ty; best.tilesX = txn; best.IH = IH; best.IW = IW;
+            best.LW = LW; best.XCHP = XCHP; best.DCP = 0; best.lds_bytes = (size_t)floats * 4; best.ok = true;
+            best.quad = 1; best.xshift = xshift; best.ef = 0; best.ga = 1;
+          }
+          break;
+        }
+      }
+    }
     for (int txn = 1; txn <= std::min(OW, 64); ++txn) {
       if (force_txn && txn != std::min(force_txn, OW)) continue;
       int TW = (int)mpa_cdiv(OW, txn);
@@ -1110,6 +1149,168 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgParams p) {
     bsum += __shfl_xor(bsum, 1, 64);
     const int co = cot * p.COT + (tid >> 1);
     if ((tid & 1) == 0 && (tid >> 1) < p.COT && co < p.Cout) out[(long)co * NtotP + p.Ntot] = bsum;
+  }
+}
+
+
+// dY-from-global variant of conv_wgrad_kernel (see conv_wgrad15g_kernel for the measurements behind it): quad geometry
+// with exact tiling in x (OW % 4 == 0, TW * tilesX == OW, TW >= 16, W % 4 == 0).  A lane's float4 of dY (4 consecutive
+// pixels of its cout row, one buffer load) is the A operand of 4 consecutive k-steps -- k-step j of a 16-pixel group
+// contracts pixels {16g + 4kq + j} -- so the B operand of tap block t sits at xoff[t] (lane part 4kq*SW) + (16g + j)*SW:
+// one address VGPR per tap block and group, immediates for j.  LDS holds the X tile only (larger pixel tiles, fewer
+// halo bytes per MFMA).  A row's last DP % 16 pixels are a tail of three ordinary k-steps (pixels {4s + kq}); steps
+// past the tile read zeros for A (and whatever finite words follow for B: 64 zeroed words of slack end the X region).
+
+template <int NBC, int NTW, bool TAIL, int SW>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_g_kernel(const WgParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* lds_x = lds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kq = lane >> 4, l16 = lane & 15;
+  const int split = blockIdx.x, ntile = blockIdx.y, cot = blockIdx.z;
+  const int khkw = p.kh * p.kw;
+  const int nblk0 = ntile * p.nPerBlock;
+  const int ci_first = nblk0 / khkw;
+  const int n_base = nblk0 + wave * NTW * 16;
+  int xoff[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    int n = n_base + t * 16 + l16;
+    if (n >= p.Ntot) n = nblk0;
+    const int ci = n / khkw, r = n - ci * khkw;
+    const int dy = r / p.kw, dx = r - dy * p.kw;
+    xoff[t] = (ci - ci_first) * p.XCHP + dy * p.LW + dx + 4 * kq * SW + p.xshift;
+  }
+  const int NtotP = p.Ntot + (p.with_bias ? 1 : 0);
+  const bool do_bias = p.with_bias && ntile == 0 && wave == 0;
+  float bs[NBC];
+  f32x4 acc[NBC][NTW];
+#pragma unroll
+  for (int i = 0; i < NBC; ++i) {
+    bs[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (tid < WGG_SLACK) lds_x[p.TX64 + tid] = 0.f;
+
+  const int tilesPerImg = p.tilesY * p.tilesX;
+  const long totalTiles = (long)p.B * tilesPerImg;
+  const int nfull = p.DP >> 4, tail = (p.DP & 15) >> 2;     // nfull >= 1; TAIL == (tail != 0)
+  const int plane = p.OH * p.OW;
+  const int loff = (l16 * plane + 4 * kq) * 4, loff_t = (l16 * plane + kq) * 4;     // bytes
+  for (long tile = split; tile < totalTiles; tile += p.S) {
+    const int b = (int)(tile / tilesPerImg);
+    const int tr = (int)(tile - (long)b * tilesPerImg);
+    const int ty = tr / p.tilesX, tx = tr - ty * p.tilesX;
+    const int oy0 = ty * p.TH, ox0 = tx * p.TW;
+    const int iy0 = oy0 * p.sh - p.ph, ix0 = ox0 * p.sw - p.pw;
+    const float* imgb = p.dy + (long)b * p.Cout * plane;
+    const int img_elems = p.Cout * plane;
+    auto dy_rsrc = [&](int cb, int py, int col, bool on) {
+      const int u = (cot * p.COT + cb * 16) * plane + (oy0 + py) * p.OW + ox0 + col;
+      const int left = (on && oy0 + py < p.OH && u < img_elems) ? (img_elems - u) * 4 : 0;
+      return __builtin_amdgcn_make_buffer_rsrc((void*)(imgb + u), 0, left, 0x00020000);
+    };
+    auto load_full = [&](float4* a, int py, int g) {
+#pragma unroll
+      for (int cb = 0; cb < NBC; ++cb)
+        a[cb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(dy_rsrc(cb, py, 16 * g, true), loff, 0, 0));
+    };
+    __syncthreads();
+    glds_stage_x16(lds_x, p.x + (long)b * p.Cin * p.H * p.W, lane, wave, p.XCH, p.IH, p.LW, p.XCHP, p.TX64, ci_first, iy0,
+                   ix0 - p.xshift, p.Cin, p.H, p.W);
+    float4 an[WGG_DEPTH][NBC];
+#pragma unroll
+    for (int d = 0; d < WGG_DEPTH; ++d) load_full(an[d], d / nfull, d % nfull);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int py = 0; py < p.TH; ++py) {
+      const float* rowp = lds_x + py * p.sh * p.LW;
+      float4 at[NBC];
+      for (int g = 0; g < nfull; ++g) {
+        float4 ac[NBC];
+#pragma unroll
+        for (int cb = 0; cb < NBC; ++cb) {
+          ac[cb] = an[0][cb];
+#pragma unroll
+          for (int d = 0; d + 1 < WGG_DEPTH; ++d) an[d][cb] = an[d + 1][cb];
+        }
+        {
+          int gd = g + WGG_DEPTH, pyd = py;
+          while (gd >= nfull) { gd -= nfull; ++pyd; }
+          if (pyd < p.TH) load_full(an[WGG_DEPTH - 1], pyd, gd);
+        }
+        if constexpr (TAIL) {
+          if (g == nfull - 1) {     // the tail's dY words: one group ahead
+#pragma unroll
+            for (int cb = 0; cb < NBC; ++cb) {
+              at[cb].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc(cb, py, 16 * nfull, true), loff_t, 0, 0));
+              at[cb].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc(cb, py, 16 * nfull + 4, tail > 1), loff_t, 0, 0));
+              at[cb].z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc(cb, py, 16 * nfull + 8, tail > 2), loff_t, 0, 0));
+              at[cb].w = 0.f;
+            }
+          }
+        }
+        if (do_bias) {
+#pragma unroll
+          for (int cb = 0; cb < NBC; ++cb) bs[cb] += (ac[cb].x + ac[cb].y) + (ac[cb].z + ac[cb].w);
+        }
+        const float* bpx[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) bpx[t] = rowp + xoff[t] + 16 * g * SW;
+#define WGG_STEP(AV, AC, J)                                                                          \
+  {                                                                                                  \
+    float bv[NTW];                                                                                   \
+    _Pragma("unroll") for (int t = 0; t < NTW; ++t) bv[t] = bpx[t][(J) * SW];                        \
+    _Pragma("unroll") for (int cb = 0; cb < NBC; ++cb)                                               \
+      _Pragma("unroll") for (int t = 0; t < NTW; ++t)                                                \
+        acc[cb][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[cb].AC, bv[t], acc[cb][t], 0, 0, 0);    \
+    __builtin_amdgcn_sched_barrier(0);   /* keeps the scheduler from hoisting every step's reads (spills) */ \
+  }
+        WGG_STEP(ac, x, 0)
+        WGG_STEP(ac, y, 1)
+        WGG_STEP(ac, z, 2)
+        WGG_STEP(ac, w, 3)
+      }
+      if constexpr (TAIL) {
+        if (do_bias) {
+#pragma unroll
+          for (int cb = 0; cb < NBC; ++cb) bs[cb] += (at[cb].x + at[cb].y) + at[cb].z;
+        }
+        const float* bpx[NTW];       // lane part kq*SW instead of 4kq*SW
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) bpx[t] = rowp + xoff[t] + (16 * nfull - 3 * kq) * SW;
+        WGG_STEP(at, x, 0)
+        WGG_STEP(at, y, 4)
+        WGG_STEP(at, z, 8)
+      }
+#undef WGG_STEP
+    }
+  }
+  // partial slice -> workspace [split][Cout][Ntot]
+  float* out = p.ws + (long)split * p.Cout * NtotP;
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const int n = n_base + t * 16 + l16;
+    if (n >= p.Ntot) continue;
+#pragma unroll
+    for (int cb = 0; cb < NBC; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = cot * p.COT + cb * 16 + kq * 4 + r;
+        if (co < p.Cout) out[(long)co * NtotP + n] = acc[cb][t][r];
+      }
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int cb = 0; cb < NBC; ++cb) {
+      float v = bs[cb];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int co = cot * p.COT + cb * 16 + l16;
+      if (kq == 0 && co < p.Cout) out[(long)co * NtotP + p.Ntot] = v;
+    }
   }
 }
 
@@ -1653,9 +1854,9 @@ int mpa_conv2d_describe_plan(const mpa_conv_desc* d, int mode, char* buf, int bu
     }
     WgPlan w = plan_wgrad(d);
     if (!w.ok) return MPA_ERR_UNSUPPORTED;
-    snprintf(buf, buflen, "wgrad<%d,%d> COT=%d coTiles=%d nPerBlock=%d nTiles=%d XCH=%d tile=%dx%d (DP %d) tiles=%dx%d S=%d quad=%d ef=%d lds=%zuB",
-             w.NBC, w.NTW, w.COT, w.coTiles, w.nPerBlock, w.nTiles, w.XCH, w.TH, w.TW, w.DP, w.tilesY, w.tilesX, w.S,
-             w.quad, w.ef, w.lds_bytes);
+    snprintf(buf, buflen, "wgrad%s<%d,%d> COT=%d coTiles=%d nPerBlock=%d nTiles=%d XCH=%d tile=%dx%d (DP %d) tiles=%dx%d S=%d quad=%d ef=%d lds=%zuB",
+             w.ga ? "_g" : "", w.NBC, w.NTW, w.COT, w.coTiles, w.nPerBlock, w.nTiles, w.XCH, w.TH, w.TW, w.DP, w.tilesY,
+             w.tilesX, w.S, w.quad, w.ef, w.lds_bytes);
     return MPA_OK;
   }
   FwdPlan f;
@@ -1754,12 +1955,26 @@ int mpa_conv2d_bwd_weight(const mpa_conv_desc* d, const float* x, const float* d
     if (pl.ef) MPA_LAUNCH((conv_wgrad_kernel<NBC_, NTW_, true>), grid, dim3(256), pl.lds_bytes, s, p);      \
     else MPA_LAUNCH((conv_wgrad_kernel<NBC_, NTW_, false>), grid, dim3(256), pl.lds_bytes, s, p);           \
   } while (0)
+#define MPA_WGG_LAUNCH(NBC_, NTW_, SW_)                                                                      \
+  do {                                                                                                      \
+    if (pl.DP & 15) MPA_LAUNCH((conv_wgrad_g_kernel<NBC_, NTW_, true, SW_>), grid, dim3(256), pl.lds_bytes, s, p);   \
+    else MPA_LAUNCH((conv_wgrad_g_kernel<NBC_, NTW_, false, SW_>), grid, dim3(256), pl.lds_bytes, s, p);    \
+  } while (0)
+  if (pl.ga) {
+    if (d->sw == 3) MPA_WGG_LAUNCH(5, 6, 3);
+    else if (pl.NBC == 1) MPA_WGG_LAUNCH(1, 16, 1);
+    else if (pl.NBC == 2 && pl.NTW == 16) MPA_WGG_LAUNCH(2, 16, 1);
+    else if (pl.NBC == 2) MPA_WGG_LAUNCH(2, 8, 1);
+    else if (pl.NBC == 4) MPA_WGG_LAUNCH(4, 6, 1);
+    else MPA_WGG_LAUNCH(5, 6, 1);
+  } else
   if (pl.NBC == 1) MPA_WG_LAUNCH(1, 16);
   else if (pl.NBC == 2 && pl.NTW == 16) MPA_WG_LAUNCH(2, 16);
   else if (pl.NBC == 2) MPA_WG_LAUNCH(2, 8);
   else if (pl.NBC == 4) MPA_WG_LAUNCH(4, 6);
   else MPA_WG_LAUNCH(5, 6);
 #undef MPA_WG_LAUNCH
+#undef MPA_WGG_LAUNCH
   int rc = mpa_launch_status();
   if (rc) return rc;
   const long n = (long)d->Cout * (pl.Ntot + 1);
