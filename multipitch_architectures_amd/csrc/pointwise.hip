@@ -129,8 +129,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
   const int g = threadIdx.x >> 6;
   float s = 0.f;
-  if (col < N)
-    for (long r = (long)blockIdx.y * 4 + g; r < rows; r += (long)gridDim.y * 4) s += x[r * N + col];
+  if (col < N) {
+    // four independent chains keep four loads in flight per thread
+    const long step = (long)gridDim.y * 4;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    long r = (long)blockIdx.y * 4 + g;
+    for (; r + 3 * step < rows; r += 4 * step) {
+      a0 += x[r * N + col];
+      a1 += x[(r + step) * N + col];
+      a2 += x[(r + 2 * step) * N + col];
+      a3 += x[(r + 3 * step) * N + col];
+    }
+    for (; r < rows; r += step) a0 += x[r * N + col];
+    s = (a0 + a1) + (a2 + a3);
+  }
   __shared__ float sh[4][64];
   sh[g][threadIdx.x & 63] = s;
   __syncthreads();
