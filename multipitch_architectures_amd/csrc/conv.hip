@@ -896,7 +896,9 @@ WgPlan plan_wgrad(const mpa_conv_desc* d) {
   // wave tile variants (cout blocks x tap blocks); many tap blocks per wave = few dY floats staged per MFMA
   const int var_nbc[5] = {1, 2, 2, 4, 5}, var_ntw[5] = {16, 8, 16, 6, 6};
   double bestcost = 1e300;
+  const char* var_env = getenv("MPA_WG_VARIANT");        // diagnostics / tests: restrict the search to one wave tile
   for (int v = 0; v < 5; ++v) {
+    if (var_env && atoi(var_env) != v) continue;
     WgPlan pl{};
     pl.OH = OH; pl.OW = OW; pl.Ntot = Ntot;
     pl.NBC = var_nbc[v]; pl.NTW = var_ntw[v];
@@ -908,7 +910,9 @@ WgPlan plan_wgrad(const mpa_conv_desc* d) {
     const double pad_eff = ((double)pl.coTiles * pl.COT / d->Cout) * ((double)pl.nTiles * pl.nPerBlock / Ntot);
     static const int force_txn = getenv("MPA_WG_TXN") ? atoi(getenv("MPA_WG_TXN")) : 0;   // diagnostics
     // dY-from-global variant: exact tiling of 4-aligned rows, stride 1 (any variant) or the head's stride 3 (<5,6>)
-    static const bool no_ga = getenv("MPA_WG_NOGA") != nullptr;
+    const char* ga_env = getenv("MPA_WG_GA");            // diagnostics / tests: "0" = never, "force" = whenever feasible
+    const bool no_ga = ga_env && ga_env[0] == '0', force_ga = ga_env && ga_env[0] == 'f';
+    bool ga_found = false;
     const bool ga_sw = d->sw == 1 || (d->sw == 3 && pl.NBC == 5);
     if (!no_ga && !force_txn && ga_sw && (OW & 3) == 0 && (d->W & 3) == 0) {
       for (int txn = 1; txn <= 16; ++txn) {
@@ -931,7 +935,9 @@ WgPlan plan_wgrad(const mpa_conv_desc* d) {
           const double words = (double)pl.XCH * IH * LW;
           const double stage = words / 256.0 * 80.0;
           const double cost = (double)ty * txn * (mfma + 0.7 * stage + 600.0) * pad_eff;
-          if (cost < bestcost) {
+          const bool take = force_ga ? (!best.ga || cost < bestcost) : cost < bestcost;
+          if (take) {
+            ga_found = true;
             bestcost = cost;
             best = pl;
             best.TH = TH; best.TW = TW; best.DP = TW; best.tilesY = ty; best.tilesX = txn; best.IH = IH; best.IW = IW;
@@ -942,6 +948,7 @@ WgPlan plan_wgrad(const mpa_conv_desc* d) {
         }
       }
     }
+    if (force_ga && (ga_found || best.ga)) continue;      // a dY-from-global plan exists: skip the LDS-staged candidates
     for (int txn = 1; txn <= std::min(OW, 64); ++txn) {
       if (force_txn && txn != std::min(force_txn, OW)) continue;
       int TW = (int)mpa_cdiv(OW, txn);

@@ -459,3 +459,74 @@ def test_conv15_backward_weight_variants(dev, case):
     _close(xg.grad, xr.grad, 2e-5, "dx")
     _close(wg.grad, wr.grad, 5e-5, "dw")
     _close(bg.grad, br.grad, 5e-5, "db")
+
+
+# Generic backward-weight, dY-from-global variant (rows that tile exactly in 4-aligned pieces of >= 16 pixels): every
+# tail length, ragged couts / cins, tap blocks that straddle input channels, and the head's stride-(1,3) geometry.
+WGG_CASES = [
+    # B, Cin, H, W, Cout, k, (sh, sw), (ph, pw)
+    (2, 5, 9, 16, 7, 9, (1, 1), (4, 4)),        # one group, no tail
+    (3, 8, 12, 20, 33, 9, (1, 1), (4, 4)),      # tail 1
+    (2, 7, 20, 24, 16, 5, (1, 1), (2, 2)),      # tail 2
+    (2, 19, 11, 28, 30, 5, (1, 1), (2, 2)),     # tail 3
+    (2, 64, 37, 108, 32, 9, (1, 1), (4, 4)),    # the model's down2 layer
+    (1, 40, 6, 36, 80, 3, (1, 1), (1, 1)),      # 80 couts: the 5-block variant
+    (2, 24, 9, 48, 80, 3, (1, 3), (1, 0)),      # head geometry: stride 3 = kernel width, OW = 16
+    (1, 128, 10, 216, 80, 3, (1, 3), (1, 0)),   # ... at the model's width (OW = 72: 4 groups + tail 2)
+    (2, 6, 8, 32, 20, 1, (1, 1), (0, 0)),       # 1x1
+]
+
+
+@pytest.mark.parametrize("case", WGG_CASES, ids=lambda c: "x".join(str(v) for v in c[:6]) + f"s{c[6][1]}")
+def test_conv_backward_weight_global_dy_variants(dev, case):
+    from multipitch_architectures_amd import ops
+    B, Cin, H, W, Cout, k, stride, pad = case
+    x = _rand((B, Cin, H, W), 31)
+    w = _rand((Cout, Cin, k, k), 32, (2.0 / (Cin * k * k)) ** 0.5)
+    b = _rand((Cout,), 33, 0.1)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv2d(xr, wr, br, stride=stride, padding=pad)
+    gy = _rand(tuple(yr.shape), 34)
+    yr.backward(gy.double())
+    xg, wg, bg = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    y = ops.conv2d(xg, wg, bg, stride, pad, ops.ACT_NONE, 0.0)
+    y.backward(gy.to(dev))
+    _close(y, yr, 2e-5, "y")
+    _close(xg.grad, xr.grad, 2e-5, "dx")
+    _close(wg.grad, wr.grad, 5e-5, "dw")
+    _close(bg.grad, br.grad, 5e-5, "db")
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("geom", [(20, 1), (32, 1), (24, 1), (48, 3)], ids=["w20-tail1", "w32-notail", "w24-tail2", "w48-stride3"])
+def test_conv_backward_weight_every_global_dy_kernel(dev, variant, geom, monkeypatch):
+    """the planner normally picks one wave-tile variant per problem by cost; pin each of the five (x tail / no tail, and
+    the stride-3 build of the 80-cout variant) with the planner's test switches so that every instantiation is checked"""
+    import ctypes
+    from multipitch_architectures_amd import _lib as L
+    W, sw = geom
+    if sw == 3 and variant != 4:
+        pytest.skip("stride 3 exists for the 80-cout variant only")
+    monkeypatch.setenv("MPA_WG_GA", "force")
+    monkeypatch.setenv("MPA_WG_VARIANT", str(variant))
+    B, Cin, H, Cout, k = 2, 21, 7, 37, 3
+    pad = (1, 1) if sw == 1 else (1, 0)
+    d = L.ConvDesc(B, Cin, H, W, Cout, k, k, 1, sw, pad[0], pad[1])
+    buf = ctypes.create_string_buffer(512)
+    assert L.load().mpa_conv2d_describe_plan(ctypes.byref(d), 2, buf, 512) == 0
+    assert buf.value.decode().startswith("wgrad_g<"), buf.value
+    x = _rand((B, Cin, H, W), 41)
+    dy_shape = (B, Cout, H, (W + 2 * pad[1] - k) // sw + 1)
+    gy = _rand(dy_shape, 42)
+    ref_w = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, k, k), gy.double(), stride=(1, sw), padding=pad)
+    dw = torch.empty(Cout, Cin, k, k, device=dev)
+    db = torch.empty(Cout, device=dev)
+    lib = L.load()
+    n = lib.mpa_conv2d_bwd_weight_workspace(ctypes.byref(d))
+    ws = torch.empty(n // 4, device=dev)
+    xg, gyg = x.to(dev), gy.to(dev)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.mpa_conv2d_bwd_weight(ctypes.byref(d), P(xg), P(gyg), P(dw), P(db), P(ws), n, st) == 0
+    _close(dw, ref_w, 5e-5, "dw")
+    _close(db, gy.double().sum((0, 2, 3)), 5e-5, "db")
