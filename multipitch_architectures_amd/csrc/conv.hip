@@ -914,12 +914,14 @@ WgPlan plan_wgrad(const mpa_conv_desc* d) {
     const bool no_ga = ga_env && ga_env[0] == '0', force_ga = ga_env && ga_env[0] == 'f';
     bool ga_found = false;
     const bool ga_sw = d->sw == 1 || (d->sw == 3 && pl.NBC == 5);
-    if (!no_ga && !force_txn && ga_sw && (OW & 3) == 0 && (d->W & 3) == 0) {
-      for (int txn = 1; txn <= 16; ++txn) {
+    const bool ga_ef = (OW & 3) || (d->W & 3);      // unaligned rows: one tile per row, <2,8> only, stride 1
+    if (!no_ga && !force_txn && ga_sw && (!ga_ef || (pl.NBC == 2 && pl.NTW == 8 && d->sw == 1))) {
+      for (int txn = 1; txn <= (ga_ef ? 1 : 16); ++txn) {
         if (OW % txn) continue;
         const int TW = OW / txn;
-        if ((TW & 3) || TW < 16) continue;
-        const int IW = (TW - 1) * d->sw + d->kw;
+        if ((!ga_ef && (TW & 3)) || TW < 16) continue;
+        const int DPg = (int)mpa_cdiv(TW, 4) * 4;
+        const int IW = (DPg - 1) * d->sw + d->kw;
         const int xshift = ((-d->pw) % 4 + 4) % 4;
         const int LW = (int)mpa_cdiv(IW + 3, 4) * 4;
         for (int THmax = std::min(OH, 64); THmax >= 1; --THmax) {
@@ -929,7 +931,8 @@ WgPlan plan_wgrad(const mpa_conv_desc* d) {
           const int IH = (TH - 1) * d->sh + d->kh;
           const int XCHP = IH * LW;
           const long floats = mpa_cdiv((long)pl.XCH * XCHP, 64) * 64 + WGG_SLACK;
-          const int ksteps = (TW >> 4) * 4 + ((TW & 15) ? 3 : 0);
+          if (ga_ef && (long)pl.XCH * IH > 256 * EDGE_MAXF) continue;
+          const int ksteps = (TW >> 4) * 4 + ((TW & 15) > 12 ? 4 : (TW & 15) ? 3 : 0);
           // per k-step: the MFMAs + one B read per tap block (+ its address add once per group); dY costs nothing here
           const double mfma = (double)TH * (ksteps * (pl.NBC * pl.NTW * 32.0 + 5.0 * pl.NTW) + 120.0);
           const double words = (double)pl.XCH * IH * LW;
@@ -940,9 +943,9 @@ WgPlan plan_wgrad(const mpa_conv_desc* d) {
             ga_found = true;
             bestcost = cost;
             best = pl;
-            best.TH = TH; best.TW = TW; best.DP = TW; best.tilesY = ty; best.tilesX = txn; best.IH = IH; best.IW = IW;
+            best.TH = TH; best.TW = TW; best.DP = DPg; best.tilesY = ty; best.tilesX = txn; best.IH = IH; best.IW = IW;
             best.LW = LW; best.XCHP = XCHP; best.DCP = 0; best.lds_bytes = (size_t)floats * 4; best.ok = true;
-            best.quad = 1; best.xshift = xshift; best.ef = 0; best.ga = 1;
+            best.quad = 1; best.xshift = xshift; best.ef = ga_ef ? 1 : 0; best.ga = 1;
           }
           break;
         }
@@ -1168,7 +1171,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgParams p) {
 // halo bytes per MFMA).  A row's last DP % 16 pixels are a tail of three ordinary k-steps (pixels {4s + kq}); steps
 // past the tile read zeros for A (and whatever finite words follow for B: 64 zeroed words of slack end the X region).
 
-template <int NBC, int NTW, bool TAIL, int SW>
+// NT: tail k-steps compiled in (0, 3, or 4 for rows with 13..15 pixels past the last full group).  EF: the width is not
+// a multiple of 4 -- one tile per row, X staged with the row-end edge fix, dY quads only 4-byte aligned, and the lanes of
+// the last tail step that lie past the row end are masked.
+template <int NBC, int NTW, int NT, int SW, bool EF = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_g_kernel(const WgParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lds_x = lds;
@@ -1202,7 +1208,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_g_kernel(const WgParams p) 
 
   const int tilesPerImg = p.tilesY * p.tilesX;
   const long totalTiles = (long)p.B * tilesPerImg;
-  const int nfull = p.DP >> 4, tail = (p.DP & 15) >> 2;     // nfull >= 1; TAIL == (tail != 0)
+  const int nfull = p.TW >> 4, rem = p.TW - 16 * nfull;     // nfull >= 1; (rem + 3) / 4 <= NT tail steps
   const int plane = p.OH * p.OW;
   const int loff = (l16 * plane + 4 * kq) * 4, loff_t = (l16 * plane + kq) * 4;     // bytes
   for (long tile = split; tile < totalTiles; tile += p.S) {
@@ -1224,12 +1230,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_g_kernel(const WgParams p) 
         a[cb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(dy_rsrc(cb, py, 16 * g, true), loff, 0, 0));
     };
     __syncthreads();
-    glds_stage_x16(lds_x, p.x + (long)b * p.Cin * p.H * p.W, lane, wave, p.XCH, p.IH, p.LW, p.XCHP, p.TX64, ci_first, iy0,
-                   ix0 - p.xshift, p.Cin, p.H, p.W);
+    const float* xb = p.x + (long)b * p.Cin * p.H * p.W;
+    glds_stage_x16<EF>(lds_x, xb, lane, wave, p.XCH, p.IH, p.LW, p.XCHP, p.TX64, ci_first, iy0, ix0 - p.xshift, p.Cin, p.H,
+                       p.W);
+    EdgeFix fx;
+    if constexpr (EF) edge_fix_load(fx, xb, tid, p.XCH, p.IH, p.LW, p.XCHP, ci_first, iy0, ix0 - p.xshift, p.Cin, p.H, p.W, p.W);
     float4 an[WGG_DEPTH][NBC];
 #pragma unroll
     for (int d = 0; d < WGG_DEPTH; ++d) load_full(an[d], d / nfull, d % nfull);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (EF) edge_fix_store(fx, lds_x);
     __syncthreads();
 
     for (int py = 0; py < p.TH; ++py) {
@@ -1248,14 +1258,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_g_kernel(const WgParams p) 
           while (gd >= nfull) { gd -= nfull; ++pyd; }
           if (pyd < p.TH) load_full(an[WGG_DEPTH - 1], pyd, gd);
         }
-        if constexpr (TAIL) {
+        if constexpr (NT > 0) {
           if (g == nfull - 1) {     // the tail's dY words: one group ahead
 #pragma unroll
             for (int cb = 0; cb < NBC; ++cb) {
-              at[cb].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc(cb, py, 16 * nfull, true), loff_t, 0, 0));
-              at[cb].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc(cb, py, 16 * nfull + 4, tail > 1), loff_t, 0, 0));
-              at[cb].z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc(cb, py, 16 * nfull + 8, tail > 2), loff_t, 0, 0));
-              at[cb].w = 0.f;
+              at[cb].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc(cb, py, 16 * nfull, rem > 0), loff_t, 0, 0));
+              at[cb].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc(cb, py, 16 * nfull + 4, rem > 4), loff_t, 0, 0));
+              at[cb].z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc(cb, py, 16 * nfull + 8, rem > 8), loff_t, 0, 0));
+              at[cb].w = NT > 3 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc(cb, py, 16 * nfull + 12, rem > 12), loff_t, 0, 0)) : 0.f;
+              if constexpr (EF) {     // pixels 16 nfull + 4s + kq >= TW belong to the next row
+                if (kq >= rem) at[cb].x = 0.f;
+                if (kq + 4 >= rem) at[cb].y = 0.f;
+                if (kq + 8 >= rem) at[cb].z = 0.f;
+                if (kq + 12 >= rem) at[cb].w = 0.f;
+              }
             }
           }
         }
@@ -1280,10 +1296,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_g_kernel(const WgParams p) 
         WGG_STEP(ac, z, 2)
         WGG_STEP(ac, w, 3)
       }
-      if constexpr (TAIL) {
+      if constexpr (NT > 0) {
         if (do_bias) {
 #pragma unroll
-          for (int cb = 0; cb < NBC; ++cb) bs[cb] += (at[cb].x + at[cb].y) + at[cb].z;
+          for (int cb = 0; cb < NBC; ++cb) bs[cb] += (at[cb].x + at[cb].y) + (at[cb].z + at[cb].w);
         }
         const float* bpx[NTW];       // lane part kq*SW instead of 4kq*SW
 #pragma unroll
@@ -1291,6 +1307,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_g_kernel(const WgParams p) 
         WGG_STEP(at, x, 0)
         WGG_STEP(at, y, 4)
         WGG_STEP(at, z, 8)
+        if constexpr (NT > 3) WGG_STEP(at, w, 12)
       }
 #undef WGG_STEP
     }
@@ -1975,9 +1992,15 @@ int mpa_conv2d_bwd_weight(const mpa_conv_desc* d, const float* x, const float* d
   } while (0)
 #define MPA_WGG_LAUNCH(NBC_, NTW_, SW_)                                                                      \
   do {                                                                                                      \
-    if (pl.DP & 15) MPA_LAUNCH((conv_wgrad_g_kernel<NBC_, NTW_, true, SW_>), grid, dim3(256), pl.lds_bytes, s, p);   \
-    else MPA_LAUNCH((conv_wgrad_g_kernel<NBC_, NTW_, false, SW_>), grid, dim3(256), pl.lds_bytes, s, p);    \
+    if (pl.TW & 15) MPA_LAUNCH((conv_wgrad_g_kernel<NBC_, NTW_, 3, SW_>), grid, dim3(256), pl.lds_bytes, s, p);      \
+    else MPA_LAUNCH((conv_wgrad_g_kernel<NBC_, NTW_, 0, SW_>), grid, dim3(256), pl.lds_bytes, s, p);        \
   } while (0)
+  if (pl.ga && pl.ef) {        // unaligned rows: <2,8>, stride 1
+    const int rem = pl.TW & 15;
+    if (rem > 12) MPA_LAUNCH((conv_wgrad_g_kernel<2, 8, 4, 1, true>), grid, dim3(256), pl.lds_bytes, s, p);
+    else if (rem) MPA_LAUNCH((conv_wgrad_g_kernel<2, 8, 3, 1, true>), grid, dim3(256), pl.lds_bytes, s, p);
+    else MPA_LAUNCH((conv_wgrad_g_kernel<2, 8, 0, 1, true>), grid, dim3(256), pl.lds_bytes, s, p);
+  } else
   if (pl.ga) {
     if (d->sw == 3) MPA_WGG_LAUNCH(5, 6, 3);
     else if (pl.NBC == 1) MPA_WGG_LAUNCH(1, 16, 1);

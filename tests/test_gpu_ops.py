@@ -474,6 +474,13 @@ WGG_CASES = [
     (2, 24, 9, 48, 80, 3, (1, 3), (1, 0)),      # head geometry: stride 3 = kernel width, OW = 16
     (1, 128, 10, 216, 80, 3, (1, 3), (1, 0)),   # ... at the model's width (OW = 72: 4 groups + tail 2)
     (2, 6, 8, 32, 20, 1, (1, 1), (0, 0)),       # 1x1
+    # widths that are not multiples of 4: one tile per row, edge-fixed X staging, masked last tail step
+    (2, 8, 10, 54, 32, 9, (1, 1), (4, 4)),      # the model's 18x54 level: 3 groups + 6 pixels
+    (2, 22, 9, 27, 40, 5, (1, 1), (2, 2)),      # 9x27 level: 1 group + 11 pixels
+    (1, 9, 7, 30, 32, 3, (1, 1), (1, 1)),       # 14 pixels past the group: four tail steps
+    (1, 4, 5, 45, 33, 5, (1, 1), (2, 2)),       # 13 pixels past the groups: four tail steps, one lane of the last
+    (2, 5, 6, 17, 16, 3, (1, 1), (1, 1)),       # a single pixel past the group
+    (2, 5, 6, 19, 16, 3, (1, 1), (0, 0)),       # valid padding: output width 17 from input width 19
 ]
 
 
@@ -498,7 +505,9 @@ def test_conv_backward_weight_global_dy_variants(dev, case):
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
-@pytest.mark.parametrize("geom", [(20, 1), (32, 1), (24, 1), (48, 3)], ids=["w20-tail1", "w32-notail", "w24-tail2", "w48-stride3"])
+@pytest.mark.parametrize("geom", [(20, 1), (32, 1), (24, 1), (48, 3), (17, 1), (27, 1), (30, 1), (45, 1), (54, 1)],
+                         ids=["w20-tail1", "w32-notail", "w24-tail2", "w48-stride3", "w17-edge", "w27-edge", "w30-edge4",
+                              "w45-edge4", "w54-edge"])
 def test_conv_backward_weight_every_global_dy_kernel(dev, variant, geom, monkeypatch):
     """the planner normally picks one wave-tile variant per problem by cost; pin each of the five (x tail / no tail, and
     the stride-3 build of the 80-cout variant) with the planner's test switches so that every instantiation is checked"""
@@ -507,6 +516,8 @@ def test_conv_backward_weight_every_global_dy_kernel(dev, variant, geom, monkeyp
     W, sw = geom
     if sw == 3 and variant != 4:
         pytest.skip("stride 3 exists for the 80-cout variant only")
+    if W % 4 and variant != 1:
+        pytest.skip("unaligned rows exist for the <2,8> variant only")
     monkeypatch.setenv("MPA_WG_GA", "force")
     monkeypatch.setenv("MPA_WG_VARIANT", str(variant))
     B, Cin, H, Cout, k = 2, 21, 7, 37, 3
