@@ -1948,7 +1948,7 @@ int mpa_conv2d_bwd_weight(const mpa_conv_desc* d, const float* x, const float* d
         attr_g = true;
       }
       const bool tl = (p15.DP & 15) != 0;
-      const bool ev = ((p15.DP >> 4) & 1) == 0 && !getenv("MPA_WG15_NOUNROLL");
+      const bool ev = ((p15.DP >> 4) & 1) == 0;
 #define MPA_WG15G_GO(...) MPA_LAUNCH((conv_wgrad15g_kernel<__VA_ARGS__>), grid15, dim3(256), p15.lds_bytes, s15, q)
       if (p15.NBC == 1) {
         if (tl) { if (ev) MPA_WG15G_GO(1, true, true); else MPA_WG15G_GO(1, true, false); }
