@@ -103,6 +103,51 @@ __global__ __launch_bounds__(256) void maxpool_fwd_plane_kernel(const float* __r
   }
 }
 
+// (KH, 1) windows, stride 1, no padding (the head's MaxPool2d((13,1)) over 75 frames): a thread owns one column and R
+// consecutive output rows, reads their R+KH-1 inputs from the LDS plane once into registers and forms the R windows
+// there -- ~35 instructions per output instead of ~150 in the generic loop (integer division, per-tap bounds tests and
+// one LDS read per tap), which was instruction-bound at 9x its HBM time.  Same first-maximum / NaN rule as above.
+template <int KH, int R>
+__global__ __launch_bounds__(256) void maxpool_col_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                              int32_t* __restrict__ idx, int H, int W, int OH, int ph) {
+  extern __shared__ float plane[];
+  const long pl = blockIdx.x;
+  const float* xp = x + pl * H * W;
+  const int n_in = H * W, n_out = OH * W;
+  if ((n_in & 3) == 0) {
+    for (int i = threadIdx.x * 4; i < n_in; i += 1024) *(float4*)(plane + i) = *(const float4*)(xp + i);
+  } else {
+    for (int i = threadIdx.x; i < n_in; i += 256) plane[i] = xp[i];
+  }
+  __syncthreads();
+  const int nblk = (OH + R - 1) / R;
+  for (int item = threadIdx.x; item < nblk * W; item += 256) {
+    const int blk = item / W, col = item - blk * W;
+    const int r0 = blk * R;              // first output row of the block; its first input row is r0 - ph
+    float v[R + KH - 1];
+#pragma unroll
+    for (int j = 0; j < R + KH - 1; ++j) {
+      const int iy = r0 - ph + j;
+      v[j] = (iy >= 0 && iy < H) ? plane[iy * W + col] : -INFINITY;
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      if (r0 + i >= OH) break;
+      const int lo = max(0, ph - (r0 + i));          // rows above the image are not part of the window
+      float best = v[i];
+      int bi = i;
+#pragma unroll
+      for (int d = 1; d < KH; ++d) {
+        const float c = v[i + d];
+        // rows below the image hold -inf and never win; the first row inside the image always starts the window
+        if (d <= lo ? d == lo : ((c > best || c != c) && r0 - ph + i + d < H)) { best = c; bi = i + d; }
+      }
+      y[pl * n_out + (long)(r0 + i) * W + col] = best;
+      if (idx) idx[pl * n_out + (long)(r0 + i) * W + col] = (r0 - ph + bi) * W + col;
+    }
+  }
+}
+
 // Scatter form inside one (b, c) plane: the gradient plane lives in LDS, every window adds its dy to its recorded argmax
 // with an LDS float atomic, then the plane is written out with contiguous stores -- one LDS operation per *window*
 // instead of kh*kw argmax tests per input element (13 for the head's 13x1 stride-1 pool).  Where several overlapping
@@ -115,9 +160,20 @@ __global__ __launch_bounds__(256) void maxpool_bwd_plane_kernel(const float* __r
   __syncthreads();
   const float* g = dy + pl * n_out;
   const int32_t* am = idx + pl * n_out;
-  for (int o = threadIdx.x; o < n_out; o += 256) {
-    const int t = am[o];
-    if (t >= 0 && t < n_in) atomicAdd(&plane[t], g[o]);
+  // eight windows per trip: sixteen independent loads in flight instead of a load -> wait -> load -> wait chain per window
+  // (that chain made this kernel 8x slower than its HBM traffic)
+  for (int o0 = threadIdx.x; o0 < n_out; o0 += 8 * 256) {
+    int t[8];
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int o = o0 + u * 256;
+      t[u] = o < n_out ? am[o] : -1;
+      v[u] = o < n_out ? g[o] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (t[u] >= 0 && t[u] < n_in) atomicAdd(&plane[t[u]], v[u]);
   }
   __syncthreads();
   float* out = dx + pl * n_in;
@@ -273,6 +329,11 @@ int mpa_maxpool2d_fwd(const float* x, float* y, int32_t* idx, int B, int C, int 
   if (OH <= 0 || OW <= 0) return MPA_ERR_ARG;
   const long planes = (long)B * C;
   if ((size_t)H * W * 4 <= PLANE_LDS_BYTES && planes <= 0x7fffffffL) {
+    if (kh == 13 && kw == 1 && sh == 1 && sw == 1 && pw == 0 && ph >= 0 && ph < 13) {
+      MPA_LAUNCH((maxpool_col_fwd_kernel<13, 8>), dim3((unsigned)planes), dim3(256), (size_t)H * W * 4, (hipStream_t)stream,
+                 x, y, idx, H, W, OH, ph);
+      return mpa_launch_status();
+    }
     MPA_LAUNCH(maxpool_fwd_plane_kernel, dim3((unsigned)planes), dim3(256), (size_t)H * W * 4, (hipStream_t)stream, x, y,
                idx, H, W, OH, OW, kh, kw, sh, sw, ph, pw);
     return mpa_launch_status();

@@ -157,7 +157,8 @@ def test_batchnorm_relu(dev, shape, training):
 POOL_CASES = [((2, 2), (2, 2), (0, 0), (3, 5, 75, 216)), ((2, 2), (2, 2), (0, 0), (2, 4, 37, 108)),
               ((2, 2), (2, 2), (0, 0), (2, 4, 9, 27)), ((3, 1), (1, 1), (1, 0), (2, 3, 75, 216)),
               ((13, 1), (1, 1), (6, 0), (2, 5, 75, 72)), ((2, 5), (1, 2), (0, 0), (2, 6, 3, 9)),
-              ((13, 1), (1, 1), (6, 0), (1, 2, 5, 4))]
+              ((13, 1), (1, 1), (6, 0), (1, 2, 5, 4)), ((13, 1), (1, 1), (0, 0), (2, 3, 75, 72)),
+              ((13, 1), (1, 1), (3, 0), (1, 2, 20, 7)), ((13, 1), (1, 1), (6, 0), (3, 2, 174, 72))]
 
 
 @pytest.mark.parametrize("k,s,p,shape", POOL_CASES)
