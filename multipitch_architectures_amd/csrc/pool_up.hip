@@ -104,31 +104,26 @@ __global__ __launch_bounds__(256) void maxpool_fwd_plane_kernel(const float* __r
 }
 
 // (KH, 1) windows, stride 1, no padding (the head's MaxPool2d((13,1)) over 75 frames): a thread owns one column and R
-// consecutive output rows, reads their R+KH-1 inputs from the LDS plane once into registers and forms the R windows
-// there -- ~35 instructions per output instead of ~150 in the generic loop (integer division, per-tap bounds tests and
+// consecutive output rows, loads their R+KH-1 inputs once (straight from global memory, coalesced along the row) into
+// registers and forms the R windows there -- ~35 instructions per output instead of ~150 in the generic loop (integer division, per-tap bounds tests and
 // one LDS read per tap), which was instruction-bound at 9x its HBM time.  Same first-maximum / NaN rule as above.
 template <int KH, int R>
 __global__ __launch_bounds__(256) void maxpool_col_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                              int32_t* __restrict__ idx, int H, int W, int OH, int ph) {
-  extern __shared__ float plane[];
-  const long pl = blockIdx.x;
-  const float* xp = x + pl * H * W;
-  const int n_in = H * W, n_out = OH * W;
-  if ((n_in & 3) == 0) {
-    for (int i = threadIdx.x * 4; i < n_in; i += 1024) *(float4*)(plane + i) = *(const float4*)(xp + i);
-  } else {
-    for (int i = threadIdx.x; i < n_in; i += 256) plane[i] = xp[i];
-  }
-  __syncthreads();
+                                                              int32_t* __restrict__ idx, long planes, int H, int W, int OH,
+                                                              int ph) {
   const int nblk = (OH + R - 1) / R;
-  for (int item = threadIdx.x; item < nblk * W; item += 256) {
-    const int blk = item / W, col = item - blk * W;
-    const int r0 = blk * R;              // first output row of the block; its first input row is r0 - ph
+  const long items = planes * nblk * W;
+  for (long item = (long)blockIdx.x * 256 + threadIdx.x; item < items; item += (long)gridDim.x * 256) {
+    const long pb = item / W;
+    const int col = (int)(item - pb * W);
+    const long pl = pb / nblk;
+    const int r0 = (int)(pb - pl * nblk) * R;     // first output row of the block; its first input row is r0 - ph
+    const float* xp = x + pl * H * W + col;
     float v[R + KH - 1];
 #pragma unroll
     for (int j = 0; j < R + KH - 1; ++j) {
       const int iy = r0 - ph + j;
-      v[j] = (iy >= 0 && iy < H) ? plane[iy * W + col] : -INFINITY;
+      v[j] = (iy >= 0 && iy < H) ? xp[(long)iy * W] : -INFINITY;
     }
 #pragma unroll
     for (int i = 0; i < R; ++i) {
@@ -142,8 +137,48 @@ __global__ __launch_bounds__(256) void maxpool_col_fwd_kernel(const float* __res
         // rows below the image hold -inf and never win; the first row inside the image always starts the window
         if (d <= lo ? d == lo : ((c > best || c != c) && r0 - ph + i + d < H)) { best = c; bi = i + d; }
       }
-      y[pl * n_out + (long)(r0 + i) * W + col] = best;
-      if (idx) idx[pl * n_out + (long)(r0 + i) * W + col] = (r0 - ph + bi) * W + col;
+      const long o = (pl * OH + r0 + i) * W + col;
+      y[o] = best;
+      if (idx) idx[o] = (r0 - ph + bi) * W + col;
+    }
+  }
+}
+
+// Backward of the same (KH, 1) stride-1 windows in gather form: a thread owns one column and R consecutive input rows,
+// loads the R+KH-1 (argmax, dy) pairs of the windows that can contain them straight from global memory (coalesced along
+// the row) and sums the ones whose argmax it is, in a fixed order -- no LDS, no atomics (LDS float atomics cost ~4 cycles
+// per lane: the scatter form below needed 590 us for 83 us of traffic), and the result is run-to-run reproducible.
+template <int KH, int R>
+__global__ __launch_bounds__(256) void maxpool_col_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ idx,
+                                                              float* __restrict__ dx, long planes, int H, int W, int OH,
+                                                              int ph) {
+  const int nblk = (H + R - 1) / R;
+  const long items = planes * nblk * W;
+  for (long item = (long)blockIdx.x * 256 + threadIdx.x; item < items; item += (long)gridDim.x * 256) {
+    const long pb = item / W;
+    const int col = (int)(item - pb * W);
+    const long pl = pb / nblk;
+    const int iy0 = (int)(pb - pl * nblk) * R;
+    const int oy0 = iy0 + ph - KH + 1;          // first window that can contain input row iy0
+    const float* g = dy + pl * OH * W + col;
+    const int32_t* am = idx + pl * OH * W + col;
+    int t[R + KH - 1];
+    float v[R + KH - 1];
+#pragma unroll
+    for (int j = 0; j < R + KH - 1; ++j) {
+      const int oy = oy0 + j;
+      const bool ok = oy >= 0 && oy < OH;
+      t[j] = ok ? am[(long)oy * W] : -1;
+      v[j] = ok ? g[(long)oy * W] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      if (iy0 + i >= H) break;
+      const int me = (iy0 + i) * W + col;
+      float sum = 0.f;
+#pragma unroll
+      for (int d = 0; d < KH; ++d) sum += t[i + d] == me ? v[i + d] : 0.f;
+      dx[(pl * H + iy0 + i) * W + col] = sum;
     }
   }
 }
@@ -328,12 +363,13 @@ int mpa_maxpool2d_fwd(const float* x, float* y, int32_t* idx, int B, int C, int 
   const int OH = (H + 2 * ph - kh) / sh + 1, OW = (W + 2 * pw - kw) / sw + 1;
   if (OH <= 0 || OW <= 0) return MPA_ERR_ARG;
   const long planes = (long)B * C;
+  if (kh == 13 && kw == 1 && sh == 1 && sw == 1 && pw == 0 && ph >= 0 && ph < 13) {
+    const long items = planes * mpa_cdiv(OH, 8) * W;
+    MPA_LAUNCH((maxpool_col_fwd_kernel<13, 8>), dim3((unsigned)std::min<long>(mpa_cdiv(items, 256), 1 << 20)), dim3(256), 0,
+               (hipStream_t)stream, x, y, idx, planes, H, W, OH, ph);
+    return mpa_launch_status();
+  }
   if ((size_t)H * W * 4 <= PLANE_LDS_BYTES && planes <= 0x7fffffffL) {
-    if (kh == 13 && kw == 1 && sh == 1 && sw == 1 && pw == 0 && ph >= 0 && ph < 13) {
-      MPA_LAUNCH((maxpool_col_fwd_kernel<13, 8>), dim3((unsigned)planes), dim3(256), (size_t)H * W * 4, (hipStream_t)stream,
-                 x, y, idx, H, W, OH, ph);
-      return mpa_launch_status();
-    }
     MPA_LAUNCH(maxpool_fwd_plane_kernel, dim3((unsigned)planes), dim3(256), (size_t)H * W * 4, (hipStream_t)stream, x, y,
                idx, H, W, OH, OW, kh, kw, sh, sw, ph, pw);
     return mpa_launch_status();
@@ -348,6 +384,12 @@ int mpa_maxpool2d_bwd(const float* dy, const int32_t* idx, float* dx, int B, int
   if (!dy || !idx || !dx) return MPA_ERR_ARG;
   const int OH = (H + 2 * ph - kh) / sh + 1, OW = (W + 2 * pw - kw) / sw + 1;
   const long planes = (long)B * C;
+  if (kh == 13 && kw == 1 && sh == 1 && sw == 1 && pw == 0 && ph >= 0 && ph < 13) {
+    const long items = planes * mpa_cdiv(H, 8) * W;
+    MPA_LAUNCH((maxpool_col_bwd_kernel<13, 8>), dim3((unsigned)std::min<long>(mpa_cdiv(items, 256), 1 << 20)), dim3(256), 0,
+               (hipStream_t)stream, dy, idx, dx, planes, H, W, OH, ph);
+    return mpa_launch_status();
+  }
   if ((size_t)H * W * 4 <= PLANE_LDS_BYTES && planes <= 0x7fffffffL) {
     MPA_LAUNCH(maxpool_bwd_plane_kernel, dim3((unsigned)planes), dim3(256), (size_t)H * W * 4, (hipStream_t)stream, dy,
                idx, dx, H * W, OH * OW);
