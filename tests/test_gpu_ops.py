@@ -542,3 +542,22 @@ def test_conv_backward_weight_every_global_dy_kernel(dev, variant, geom, monkeyp
     assert lib.mpa_conv2d_bwd_weight(ctypes.byref(d), P(xg), P(gyg), P(dw), P(db), P(ws), n, st) == 0
     _close(dw, ref_w, 5e-5, "dw")
     _close(db, gy.double().sum((0, 2, 3)), 5e-5, "db")
+
+
+def test_maxpool_head_window_nan_and_ties(dev):
+    """the head's (13,1) column kernel has a fast path for interior blocks without NaNs: NaNs must still propagate like
+    torch's, and ties must still pick the first maximum"""
+    from multipitch_architectures_amd import ops
+    x = _rand((2, 3, 75, 72), 5)
+    x[0, 1, 30, 7] = float("nan")
+    x[1, 2, 40:50, 11] = 2.5            # a run of equal maxima inside one column
+    yr = F.max_pool2d(x, (13, 1), (1, 1), (6, 0))
+    y = ops.max_pool2d(x.to(dev), (13, 1), (1, 1), (6, 0)).cpu()
+    assert torch.equal(torch.isnan(y), torch.isnan(yr))
+    assert torch.equal(torch.nan_to_num(y, nan=0.0), torch.nan_to_num(yr, nan=0.0))
+    xr = x.clone(); xr[0, 1, 30, 7] = 0.0
+    a = xr.clone().requires_grad_(True)
+    F.max_pool2d(a, (13, 1), (1, 1), (6, 0)).sum().backward()
+    b = xr.to(dev).requires_grad_(True)
+    ops.max_pool2d(b, (13, 1), (1, 1), (6, 0)).sum().backward()
+    assert torch.equal(b.grad.cpu(), a.grad)
