@@ -14,10 +14,74 @@ import os
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="SAUnet:L")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="default: the batch BASELINE.json quotes for the configuration (256 for SAUnet:L)")
+    ap.add_argument("--frames", type=int, default=75)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying "
+                    "the captured HIP graph of the step")
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: this process becomes the parent of N fresh rank processes (one per
+    GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, the same command line) and only waits for them.
+    It runs before torch is imported here, so the parent never touches a GPU and no process that has initialised HIP is
+    ever re-executed.  Rank 0 inherits stdout and prints the JSON line; any failing rank takes the others down and its
+    exit code becomes ours."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
+    rc = 0
+    try:
+        live = list(procs)
+        while live and rc == 0:
+            time.sleep(0.2)
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0:
+                    rc = code if code > 0 else 1
+                    print(f"bench.py: rank {procs.index(p)} exited with {code}; stopping the other ranks",
+                          file=sys.stderr, flush=True)
+                    break
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except Exception:       # noqa: BLE001 -- a rank that ignores SIGTERM
+                p.kill()
+    return rc
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    _args = parse_args()
+    if _args.gpus > 1:
+        sys.exit(spawn_ranks(_args.gpus))
+
+import torch  # noqa: E402  (after the spawn decision: the parent of an N>1 run never loads it)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X dense fp32-input MFMA peak (MI355X_MICROARCH.md, chip table)
 
@@ -135,19 +199,11 @@ def eval_measures_probe(with_cpu, n_frames=20000):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="SAUnet:L")
-    ap.add_argument("--global-batch", type=int, default=256)
-    ap.add_argument("--frames", type=int, default=75)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    args = parse_args()
 
     import torch.distributed as dist
     from multipitch_architectures_amd import nn_models, ops
-    from multipitch_architectures_amd.configs import CONFIGS, TRAIN_GFLOP_PER_PATCH
+    from multipitch_architectures_amd.configs import BASELINE_CONFIGS, CONFIGS, TRAIN_GFLOP_PER_PATCH
     from multipitch_architectures_amd.losses import BCELoss, PolyphonyLoss
     from multipitch_architectures_amd.optim import AdamW
     from multipitch_architectures_amd.parallel import GradientAverager, shard_range
@@ -157,7 +213,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size must equal --gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     # one process per GPU; MPA_DIST_BACKEND=gloo + fewer devices than ranks is only for rehearsing the N>1 code path
@@ -176,6 +232,9 @@ def main():
             dist.init_process_group(backend)
 
     cfg = CONFIGS[args.config]
+    baseline_batch = dict(BASELINE_CONFIGS)
+    if args.global_batch is None:
+        args.global_batch = baseline_batch.get(args.config, 256)
     torch.manual_seed(0)                                    # PyTorch default init, seed 0 (timing is value independent)
     model = getattr(nn_models, cfg["cls"])(**cfg["kwargs"]).to(dev).train()
     if world > 1:
@@ -231,6 +290,13 @@ def main():
         dt = float(t.item())
     probe_ms = ops.probe_results_ms()
     ops.set_kernel_probe(None)
+    # which device every rank actually ran on (gathered, so the line proves N distinct GPUs took part)
+    props = torch.cuda.get_device_properties(dev)
+    mine = {"rank": rank, "device": str(dev), "name": props.name, "pci_bus_id": getattr(props, "pci_bus_id", None)}
+    devices = [mine]
+    if world > 1:
+        devices = [None] * world
+        dist.all_gather_object(devices, mine)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -252,9 +318,13 @@ def main():
             "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic", "patches_per_s": patches_per_s, "loss": float(loss.detach()),
+            "ranks_seen": dist.get_world_size() if world > 1 else 1, "devices": devices,
+            "dist_backend": backend if world > 1 else None,
             "config": {"workload": f"{args.config} ({cfg['cls']}) train step fwd+bwd+AdamW, global batch "
                                    f"{args.global_batch}, patches (6,{args.frames},216) -> ({args.frames - 74},72), "
-                                   f"BASELINE.json configs[3]", "global_batch": args.global_batch,
+                                   + (f"BASELINE.json configs[{[c for c, _ in BASELINE_CONFIGS].index(args.config)}]"
+                                      if args.config in baseline_batch and args.global_batch == baseline_batch[args.config]
+                                      else "not a BASELINE.json configuration"), "global_batch": args.global_batch,
                        "frames": args.frames, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,

@@ -217,3 +217,19 @@ def test_planner_invariants_on_random_geometries():
         assert lib.mpa_conv2d_bwd_weight_workspace(ctypes.byref(d)) > 0
         seen += 1
     assert seen > 250
+
+
+def test_bench_spawns_its_own_ranks_and_fails_loudly_without_gpus():
+    """`python bench.py --gpus 2` with no launcher: the parent starts two rank processes (never touching a GPU itself)
+    and returns non-zero when they fail -- here because this box has no MI355X and there is no CPU fallback."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() > 0:
+        pytest.skip("would start a real 2-rank run on this box; covered by tests/test_gpu_parallel.py there")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert r.stderr.count("needs an MI355X") >= 1 and "stopping the other ranks" in r.stderr
+    assert r.stdout.strip() == ""

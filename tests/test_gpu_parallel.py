@@ -1,0 +1,68 @@
+"""Data-parallel path on the GPU: two ranks of the HIP models with `parallel.GradientAverager`.
+
+* RCCL ("nccl" backend), one rank per GPU -- needs two visible devices, skipped on a one-GPU box;
+* gloo with both ranks sharing device 0 -- the same hooks, buckets, stream ordering and `mpa_scale` on HIP tensors, only
+  the transport differs; this is the variant a one-GPU box can run.
+Each rank is a fresh process (tests/ddp_worker.py): nothing here re-executes a process that has touched the GPU.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _run(backend, case, world=2):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "ddp_worker.py"), backend, case], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = []
+    for p in procs:
+        try:
+            so, se = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, se[-2000:]
+        line = [ln for ln in so.splitlines() if ln.startswith("DDP_RESULT ")][-1]
+        res.append(json.loads(line[len("DDP_RESULT "):]))
+    return sorted(res, key=lambda d: d["rank"])
+
+
+def _backends():
+    out = [pytest.param("gloo", id="gloo-shared-device")]
+    out.append(pytest.param("nccl", id="rccl", marks=pytest.mark.skipif(
+        torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank; this box shows fewer than 2")))
+    return out
+
+
+@pytest.mark.parametrize("backend", _backends())
+def test_averaged_shard_gradients_equal_full_batch_gradients(backend):
+    res = _run(backend, "grads")
+    assert [r["world"] for r in res] == [2, 2]
+    assert res[0]["buckets"] > 1                       # several buckets in flight
+    for r in res:
+        assert r["rel_err"] < 2e-5, r                 # fp32 summation order only
+    if backend == "nccl":
+        assert res[0]["device"] != res[1]["device"]
+
+
+@pytest.mark.parametrize("backend", _backends())
+def test_two_rank_train_steps_keep_parameters_identical(backend):
+    res = _run(backend, "step")
+    for r in res:
+        assert r["params_identical"] and r["finite"], r
+        assert all(0 < v < 10 for v in r["losses"])
