@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--val", nargs="*", default=[]), ap.add_argument("--test", nargs="*", default=[])
     ap.add_argument("--epochs", type=int, default=100)
     ap.add_argument("--frames", type=int, default=1500)
+    ap.add_argument("--variant", default="Exp1", choices=sorted(experiment.VARIANTS),
+                    help="Exp1: stride 50, whole epochs; Exp2 ('moresamples'/RETRAIN scripts): stride 20, epochs capped "
+                         "after n_batches > 3800")
     ap.add_argument("--out", default=None, help="path of the best-model checkpoint (bare state_dict, as the scripts save it)")
     args = ap.parse_args()
     logging.basicConfig(level=logging.INFO, format="%(message)s")
@@ -54,7 +57,8 @@ def main():
         val_files, test_files = pick(args.val), pick(args.test)
         names = [n for n in all_names if any(v in n for v in args.test)]
         train_files = [f for f, n in zip(all_files, all_names) if not any(v in n for v in args.val + args.test)]
-    experiment.train(model, criterion, train_files, val_files, lr=cfg["lr"], max_epochs=args.epochs, path_trained_model=args.out)
+    experiment.train(model, criterion, train_files, val_files, lr=cfg["lr"], max_epochs=args.epochs, path_trained_model=args.out,
+                     variant=args.variant)
     if args.out:
         model.load_state_dict(torch.load(args.out))
     experiment.test(model, test_files, names)

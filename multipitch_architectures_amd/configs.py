@@ -19,17 +19,34 @@ CONFIGS = {
     # paper name      class                                   kwargs
     "CNN:XS": _c("basic_cnn_segm_sigmoid", n_chan_layers=[20, 20, 10, 1]),                       # exp126a
     "CNN:S": _c("basic_cnn_segm_sigmoid", n_chan_layers=[100, 100, 50, 10]),                     # exp126b
+    "CNN:M": _c("basic_cnn_segm_sigmoid", n_chan_layers=[250, 150, 100, 100]),                   # exp126c
+    "CNN:L": _c("basic_cnn_segm_sigmoid", n_chan_layers=[280, 180, 120, 100]),                   # exp126d
     "DCNN:S": _c("deep_cnn_segm_sigmoid", n_chan_layers=[20, 20, 10, 1], n_prefilt_layers=5, residual=False),  # exp127a
+    "DCNN:M": _c("deep_cnn_segm_sigmoid", lr=2e-4, n_chan_layers=[40, 40, 30, 10], n_prefilt_layers=5, residual=False),  # exp127b
+    "DCNN:L": _c("deep_cnn_segm_sigmoid", lr=2e-4, n_chan_layers=[70, 70, 50, 10], n_prefilt_layers=5, residual=False),  # exp127c
     "DRCNN:S": _c("deep_cnn_segm_sigmoid", n_chan_layers=[20, 20, 10, 1], n_prefilt_layers=5, residual=True),  # exp128a
+    "DRCNN:M": _c("deep_cnn_segm_sigmoid", lr=2e-4, n_chan_layers=[40, 40, 30, 10], n_prefilt_layers=5, residual=True),  # exp128b
     "DRCNN:L": _c("deep_cnn_segm_sigmoid", lr=2e-4, n_chan_layers=[70, 70, 50, 10], n_prefilt_layers=5, residual=True),  # exp128c
     "Unet:S": _c("simple_u_net_largekernels", n_chan_layers=[64, 30, 20, 10], scalefac=8),       # exp160d2
+    "Unet:M": _c("simple_u_net_largekernels", n_chan_layers=[128, 100, 80, 50], scalefac=8),     # exp160g
     "Unet:L": _c("simple_u_net_largekernels", n_chan_layers=[128, 150, 100, 80], scalefac=4),    # exp160e3
+    "Unet:XL": _c("simple_u_net_largekernels", n_chan_layers=[128, 180, 150, 100], scalefac=2),  # exp160f
     "SAUnet:M": _c("simple_u_net_doubleselfattn", n_chan_layers=[64, 30, 20, 10], scalefac=8, embed_dim=64,
                    num_heads=8, mlp_dim=1024, pos_encoding="sinusoidal"),                        # exp180b
     "SAUnet:L": _c("simple_u_net_doubleselfattn", n_chan_layers=[128, 80, 50, 30], scalefac=4, embed_dim=128,
                    num_heads=8, mlp_dim=8192, pos_encoding="sinusoidal"),                        # exp180d
+    "SAUnet:XL": _c("simple_u_net_doubleselfattn", n_chan_layers=[128, 200, 150, 150], scalefac=2, embed_dim=256,
+                    num_heads=8, mlp_dim=8192, pos_encoding="sinusoidal"),                       # exp180e
+    "SAUnet:XXL": _c("simple_u_net_doubleselfattn", n_chan_layers=[128, 200, 150, 150], scalefac=4, embed_dim=128,
+                     num_heads=8, mlp_dim=8192, pos_encoding="sinusoidal"),                      # exp180f
+    "SAUSnet:M": _c("simple_u_net_doubleselfattn_twolayers", n_chan_layers=[64, 30, 20, 10], scalefac=8,
+                    embed_dim=64, num_heads=8, mlp_dim=512, pos_encoding="sinusoidal"),          # exp181b
     "SAUSnet:L": _c("simple_u_net_doubleselfattn_twolayers", n_chan_layers=[128, 80, 50, 30], scalefac=4,
                     embed_dim=128, num_heads=8, mlp_dim=4096, pos_encoding="sinusoidal"),        # exp181d
+    "SAUSnet:XL": _c("simple_u_net_doubleselfattn_twolayers", n_chan_layers=[128, 200, 150, 150], scalefac=4,
+                     embed_dim=128, num_heads=8, mlp_dim=8192, pos_encoding="sinusoidal"),       # exp181f
+    "SAUSnet:XXL": _c("simple_u_net_doubleselfattn_twolayers", n_chan_layers=[128, 200, 150, 150], scalefac=2,
+                      embed_dim=256, num_heads=8, mlp_dim=8192, pos_encoding="sinusoidal"),      # exp181e
     "BLUnet:M": _c("u_net_blstm_varlayers", n_chan_layers=[64, 30, 20, 10], scalefac=16, embed_dim=416,
                    hidden_size=208, lstm_depth=1, lstm_number=1),                                # exp186b
     "BLUnet:L": _c("u_net_blstm_varlayers", n_chan_layers=[128, 80, 50, 30], scalefac=8, embed_dim=832,
@@ -38,6 +55,8 @@ CONFIGS = {
                      hidden_size=832, lstm_depth=1, lstm_number=1),                              # exp186e
     "PUnet:M": _c("simple_u_net_polyphony_classif_softmax", n_chan_layers=[128, 100, 80, 50], scalefac=8,
                   num_polyphony_steps=24),                                                       # exp195g
+    "PUnet:L": _c("simple_u_net_polyphony_classif_softmax", n_chan_layers=[128, 150, 100, 80], scalefac=4,
+                  num_polyphony_steps=24),                                                       # exp195e3
     "PUnet:XL": _c("simple_u_net_polyphony_classif_softmax", n_chan_layers=[128, 180, 150, 100], scalefac=2,
                    num_polyphony_steps=24),                                                      # exp195f
     # ---- build-side reductions for fast parity tests (same classes, small channel counts)

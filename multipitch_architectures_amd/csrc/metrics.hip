@@ -3,9 +3,12 @@
 // with libfmp/c5/c5s2_chord_rec_template.py:238-261 (compute_eval_measures) and
 // libfmp/c3/c3s1_post_processing.py:60-68 (normalize_feature_sequence, norm '2').  Arithmetic in float64 like the
 // reference's numpy code; inputs are the fp32 targets / network outputs.  HBM-bound and tiny; the two ranking measures
-// sort the N*K scores once (hipCUB radix sort) and reduce over groups of tied scores.
+// sort the N*K scores once (rocPRIM device radix sort) and reduce over groups of tied scores.
 #include "mpa_common.h"
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/functional.hpp>
 #include <math.h>
 
 namespace {
@@ -140,9 +143,9 @@ static inline size_t up(size_t x) { return (x + 255) & ~(size_t)255; }
 static int make_layout(long n, Layout& L) {
   size_t b_sort = 0, b_sum = 0, b_max = 0;
   const float* kf = nullptr; float* kfo = nullptr; const uint32_t* ui = nullptr; uint32_t* uo = nullptr;
-  if (hipcub::DeviceRadixSort::SortPairsDescending(nullptr, b_sort, kf, kfo, kf, kfo, (int)n) != hipSuccess) return MPA_ERR_LAUNCH;
-  if (hipcub::DeviceScan::InclusiveSum(nullptr, b_sum, ui, uo, (int)n) != hipSuccess) return MPA_ERR_LAUNCH;
-  if (hipcub::DeviceScan::InclusiveScan(nullptr, b_max, ui, uo, MaxOp(), (int)n) != hipSuccess) return MPA_ERR_LAUNCH;
+  if (rocprim::radix_sort_pairs_desc(nullptr, b_sort, kf, kfo, kf, kfo, (size_t)n) != hipSuccess) return MPA_ERR_LAUNCH;
+  if (rocprim::inclusive_scan(nullptr, b_sum, ui, uo, (size_t)n, rocprim::plus<uint32_t>()) != hipSuccess) return MPA_ERR_LAUNCH;
+  if (rocprim::inclusive_scan(nullptr, b_max, ui, uo, (size_t)n, MaxOp()) != hipSuccess) return MPA_ERR_LAUNCH;
   size_t o = 0;
   L.key = o; o += up(n * 4);
   L.lab = o; o += up(n * 4);
@@ -194,14 +197,14 @@ extern "C" int mpa_eval_measures(const float* targ, const float* pred, int64_t n
   if ((rc = mpa_launch_status()) != MPA_OK) return rc;
 
   (void)hipGetLastError();
-  if (hipcub::DeviceRadixSort::SortPairsDescending(cub, cb, pred, key, targ, lab, (int)n, 0, 32, st) != hipSuccess) return MPA_ERR_LAUNCH;
+  if (rocprim::radix_sort_pairs_desc(cub, cb, pred, key, targ, lab, (size_t)n, 0, 32, st) != hipSuccess) return MPA_ERR_LAUNCH;
   const int nbel = (int)((n + 255) / 256 < MAXB ? (n + 255) / 256 : MAXB);
   MPA_LAUNCH(rank_marks_kernel, dim3(nbel), dim3(256), 0, st, key, lab, labu, start, n);
   if ((rc = mpa_launch_status()) != MPA_OK) return rc;
   cb = L.cub_bytes;
-  if (hipcub::DeviceScan::InclusiveSum(cub, cb, labu, tps, (int)n, st) != hipSuccess) return MPA_ERR_LAUNCH;
+  if (rocprim::inclusive_scan(cub, cb, labu, tps, (size_t)n, rocprim::plus<uint32_t>(), st) != hipSuccess) return MPA_ERR_LAUNCH;
   cb = L.cub_bytes;
-  if (hipcub::DeviceScan::InclusiveScan(cub, cb, start, labu, MaxOp(), (int)n, st) != hipSuccess) return MPA_ERR_LAUNCH;
+  if (rocprim::inclusive_scan(cub, cb, start, labu, (size_t)n, MaxOp(), st) != hipSuccess) return MPA_ERR_LAUNCH;
   MPA_LAUNCH(rank_groups_kernel, dim3(nbel), dim3(256), 0, st, key, tps, labu, n, prank);
   if ((rc = mpa_launch_status()) != MPA_OK) return rc;
   MPA_LAUNCH(eval_final_kernel, dim3(1), dim3(256), 0, st, prow, nbrow, prank, nbel, tps, (long)n_frames, n_bins, out);

@@ -36,6 +36,13 @@ VAL_DATASET_PARAMS = {"context": 75, "stride": 50, "compression": 10}
 TEST_DATASET_PARAMS = {"context": 75, "stride": 1, "compression": 10}
 EVAL_THRESH = 0.4
 
+# What differs between the experiment families (everything else -- batch sizes, optimiser, scheduler, early stopping,
+# measures -- is identical in all 111 scripts):
+#   Exp1 (Section IV-B)        stride 50 for train / val, whole epochs                       exp180d...py:38-50
+#   Exp2 (Section IV-C, "moresamples" / RETRAIN*)  stride 20 and an epoch ends after the batch that makes
+#        n_batches > 3800, i.e. after at most 3801 batches                                   RETRAIN_exp180d...py:38-50,337-338
+VARIANTS = {"Exp1": {"stride": 50, "max_batches": None}, "Exp2": {"stride": 20, "max_batches": 3800}}
+
 
 def build(config, device="cuda:0"):
     cfg = CONFIGS[config]
@@ -48,10 +55,17 @@ def build(config, device="cuda:0"):
 
 
 def train(model, criterion, train_files, val_files, lr=1e-3, max_epochs=100, batch_sizes=(25, 50), seed=0,
-          path_trained_model=None, log=logging.info, rank=0, world=1, averager=None):
-    """train_files / val_files: lists of (inputs (6,T,216), targets (T,n_out)) pairs.  Returns the per-epoch history."""
-    train_sets = [dataset_context(i, t, dict(TRAIN_DATASET_PARAMS), seed=seed + k) for k, (i, t) in enumerate(train_files)]
-    val_sets = [dataset_context(i, t, dict(VAL_DATASET_PARAMS)) for i, t in val_files]
+          path_trained_model=None, log=logging.info, rank=0, world=1, averager=None, variant="Exp1", stride=None,
+          max_batches=None):
+    """train_files / val_files: lists of (inputs (6,T,216), targets (T,n_out)) pairs.  Returns the per-epoch history.
+    ``variant`` picks the experiment family's stride and per-epoch batch cap (``VARIANTS``); ``stride`` /
+    ``max_batches`` override it."""
+    var = VARIANTS[variant]
+    stride = var["stride"] if stride is None else stride
+    max_batches = var["max_batches"] if max_batches is None else max_batches
+    train_sets = [dataset_context(i, t, dict(TRAIN_DATASET_PARAMS, stride=stride), seed=seed + k)
+                  for k, (i, t) in enumerate(train_files)]
+    val_sets = [dataset_context(i, t, dict(VAL_DATASET_PARAMS, stride=stride)) for i, t in val_files]
     train_loader = ContextLoader(train_sets, batch_sizes[0], shuffle=True, seed=seed, rank=rank, world=world)
     val_loader = ContextLoader(val_sets, batch_sizes[1], shuffle=False)
     optimizer = AdamW(model.parameters(), lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, amsgrad=False)
@@ -72,6 +86,8 @@ def train(model, criterion, train_files, val_files, lr=1e-3, max_epochs=100, bat
             optimizer.step()
             accum_loss += loss.item()
             n_batches += 1
+            if max_batches is not None and n_batches > max_batches:       # RETRAIN_exp180d...py:337-338
+                break
         train_loss = accum_loss / max(n_batches, 1)
         accum_val_loss, n_val = 0.0, 0
         with torch.no_grad():          # still train mode, as in the scripts: BN batch statistics, running stats move

@@ -295,8 +295,14 @@ def simple_u_net_doubleselfattn_twolayers(sd, x, train=False, taps=None, a_lrelu
 
 def u_net_blstm_varlayers(sd, x, train=False, taps=None, a_lrelu=0.3, p_dropout=0.2, hidden_size=512,
                           lstm_depth=0, lstm_number=2, **_):
-    """unet_cnns.py:1078-1101 for lstm_depth in {0,1} (the only depths any experiment uses)."""
-    assert lstm_depth <= 1, "oracle restates lstm_depth<=1 (exp186b/d/e)"
+    """unet_cnns.py:1078-1101.  lstm_depth in {0,1} are the only depths that can run at all: `lstm4` (:1037-1038) is built
+    with the same embed_dim as `lstm5`, but the skip x4 it receives (:1088) has C*27 features against x5's C*13, so for
+    lstm_depth > 1 the reference's nn.LSTM raises RuntimeError("input.size(-1) must be equal to input_size ...") on the
+    first forward (checked against the imported reference) -- restated here as the same exception type."""
+    if lstm_depth > 1:
+        x4_features = sd["down3.1.double_conv.4.weight"].shape[0] * (x.shape[3] // 8)
+        raise RuntimeError(f"input.size(-1) must be equal to input_size. Expected {sd['lstm4.blstm.weight_ih_l0'].shape[1]}, "
+                           f"got {x4_features}")
     bott = (lambda x5: blstm_temporal_enc_layer(x5, sd, "lstm5", hidden_size, lstm_number)) if lstm_depth > 0 else None
     return _unet(sd, x, train, taps, a_lrelu, p_dropout, bottleneck=bott)[0]
 

@@ -68,3 +68,15 @@ def test_eval_forward_vs_oracle_default_init(dev, name, B):
     a = (res[0] if isinstance(res, tuple) else res).cpu().numpy()
     b = (ref[0] if isinstance(ref, tuple) else ref).numpy()
     assert np.abs(a - b).max() <= 1e-4
+
+
+def test_blunet_lstm_depth_above_one_raises_like_the_reference(dev):
+    """lstm_depth > 1 constructs but cannot run: `lstm4` is built for x5's C*13 features and is fed x4's C*27
+    (unet_cnns.py:1037-1038,1088) -- the reference raises RuntimeError there, and so does the HIP model (never a silent
+    reshape)."""
+    model = nn_models.u_net_blstm_varlayers(n_chan_input=6, n_chan_layers=[8, 8, 6, 4], n_bins_in=216, n_bins_out=72,
+                                            scalefac=16, embed_dim=416, hidden_size=208, lstm_depth=2,
+                                            lstm_number=1).to(dev).eval()
+    x, _ = synth_batch(1, 75)
+    with pytest.raises(RuntimeError, match="embed_dim"):
+        model(x.to(dev))

@@ -34,3 +34,24 @@ def test_runner_trains_and_tests_on_synthetic_recordings(tmp_path):
     assert set(mean) == set(experiment.MEASURES) and all(np.isfinite(v) for v in mean.values())
     assert 0.0 < mean["roc_auc_measure"] <= 1.0
     assert any(l.startswith("Mean f_measure:   ") for l in lines) and any(l.startswith("Framewise ") for l in lines)
+
+
+def test_exp2_variant_uses_stride_20_and_caps_the_epoch(monkeypatch):
+    """Exp2 ('moresamples' / RETRAIN scripts): stride 20 for train and val, and an epoch ends after the batch that makes
+    n_batches > cap (RETRAIN_exp180d...py:38-50, 337-338) -- with cap 3 that is 4 optimiser steps per epoch."""
+    from multipitch_architectures_amd import experiment
+    from multipitch_architectures_amd.synth import synth_file
+    assert experiment.VARIANTS["Exp2"] == {"stride": 20, "max_batches": 3800}
+    assert experiment.VARIANTS["Exp1"] == {"stride": 50, "max_batches": None}
+    torch.manual_seed(0)
+    model, criterion, cfg = experiment.build("tiny:CNN")
+    seen, steps = [], []
+    real_ds = experiment.dataset_context
+    monkeypatch.setattr(experiment, "dataset_context", lambda i, t, p, **kw: (seen.append(p["stride"]), real_ds(i, t, p, **kw))[1])
+    real_step = experiment.AdamW.step
+    monkeypatch.setattr(experiment.AdamW, "step", lambda self, *a, **k: (steps.append(1), real_step(self, *a, **k))[1])
+    files = [synth_file(frames=1200, seed=1)]
+    hist = experiment.train(model, criterion, files, files, max_epochs=2, variant="Exp2", max_batches=3,
+                            log=lambda *_: None)
+    assert seen == [20, 20] and len(hist) == 2
+    assert len(steps) == 2 * 4                       # ceil(1126 / 20) = 57 patches = 3 batches of 25 would be uncapped

@@ -374,6 +374,35 @@ def test_transformer_layer_against_torch_modules(dev):
         _close(p.grad, sd["L." + k].grad, 2e-4, k)
 
 
+def test_transformer_layer_learnable_positional_table_gradient(dev):
+    """pos_encoding='learnable' (unet_cnns.py:126-129, :150-152): the table is an nn.Parameter of 600 rows of which the
+    first S receive sum_b dy, the others exactly zero -- forward and every gradient against the float64 oracle"""
+    from multipitch_architectures_amd.nn_models import transformer_enc_layer
+    from oracle import restate
+    from multipitch_architectures_amd.synth import det_fill
+    E, h, M = 32, 8, 64
+    layer = transformer_enc_layer(embed_dim=E, num_heads=h, mlp_dim=M, p_dropout=0.0, pos_encoding="learnable")
+    sd0 = det_fill(layer.state_dict())
+    sd0["pe"] = _rand(tuple(layer.pe.shape), 5, 0.3)
+    layer.load_state_dict(sd0)
+    x = _rand((5, E, 4, 13), 1)
+    sd = {"L." + k: v.double().requires_grad_(True) for k, v in layer.state_dict().items()}
+    xr = x.double().requires_grad_(True)
+    ref = restate.transformer_enc_layer(xr, sd, "L", h, True, 0.0, "learnable")
+    gy = _rand(tuple(ref.shape), 2)
+    ref.backward(gy.double())
+    layer.to(dev).train()
+    xg = x.to(dev).requires_grad_(True)
+    y = layer(xg)
+    y.backward(gy.to(dev))
+    _close(y, ref, 3e-5)
+    _close(xg.grad, xr.grad, 1e-4)
+    for k, p in layer.named_parameters():
+        _close(p.grad, sd["L." + k].grad, 2e-4, k)
+    assert layer.pe.grad.shape == (600, E)
+    assert float(layer.pe.grad[52:].abs().max()) == 0.0 and float(layer.pe.grad[:52].abs().max()) > 0.0
+
+
 def _fuzz_conv_cases(n=48, seed=20261003):
     """random small problems: odd widths (16-byte staging with the row-end edge fix), channel counts that are not
     multiples of the chunk size, strides, one-sided padding, batch sizes that trigger the channel split"""

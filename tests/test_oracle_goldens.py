@@ -165,3 +165,19 @@ def test_oracle_float64_is_exactly_the_reference(case):
             mine = grads[k].numpy().ravel()[sample_idx(grads[k].numel(), 16)]
             scale = max(float(g[f"grad64.{k}.absmax"]), 1e-12)
             assert np.abs(mine - g[f"grad64.{k}.samples"]).max() <= 1e-8 * scale + 1e-12, k
+
+
+def test_blunet_lstm_depth_above_one_raises_like_the_reference():
+    """u_net_blstm_varlayers(lstm_depth>1): `lstm4` is built for embed_dim = C*13 but receives the skip x4 with C*27
+    features, so the reference's nn.LSTM raises RuntimeError on the first forward (verified by importing the reference:
+    "input.size(-1) must be equal to input_size. Expected 416, got 864").  The oracle restates that; the product's
+    check is in tests/test_gpu_configs.py."""
+    from multipitch_architectures_amd import nn_models
+    kw = dict(n_chan_input=6, n_chan_layers=[8, 8, 6, 4], n_bins_in=216, n_bins_out=72, scalefac=16, embed_dim=416,
+              hidden_size=208, lstm_depth=2, lstm_number=1)
+    model = nn_models.u_net_blstm_varlayers(**kw)                        # constructs, like the reference
+    sd = model.state_dict()
+    assert "lstm4.blstm.weight_ih_l0" in sd and tuple(sd["lstm4.blstm.weight_ih_l0"].shape) == (4 * 208, 416)
+    x, _ = synth_batch(1, 75)
+    with pytest.raises(RuntimeError, match="Expected 416, got 864"):
+        restate.u_net_blstm_varlayers(sd, x, **kw)
