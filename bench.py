@@ -83,6 +83,7 @@ if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
 
 import torch  # noqa: E402  (after the spawn decision: the parent of an N>1 run never loads it)
 
+PROBE_STEPS = 3
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X dense fp32-input MFMA peak (MI355X_MICROARCH.md, chip table)
 
 
@@ -207,6 +208,7 @@ def main():
     from multipitch_architectures_amd.losses import BCELoss, PolyphonyLoss
     from multipitch_architectures_amd.optim import AdamW
     from multipitch_architectures_amd.parallel import GradientAverager, shard_range
+    from multipitch_architectures_amd.step import TrainStep
     from multipitch_architectures_amd.synth import synth_batch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -250,17 +252,14 @@ def main():
     x, y = x[lo:hi].to(dev), y[lo:hi].to(dev)               # inputs resident in HBM before the timed region
     ops.manual_seed(1234 + rank)
 
-    def step():
-        res = model(x)
-        loss = loss_fn(res[0], res[1], y) if is_punet else loss_fn(res, y)
-        opt.zero_grad()
-        loss.backward()
-        if averager is not None:
-            averager.finish()
-        opt.step()
-        return loss
+    criterion = (lambda res, t: loss_fn(res[0], res[1], t)) if is_punet else loss_fn
+    # the reference's loop body; replayed as one captured HIP graph after the first (eager) steps unless --no-graph
+    train_step = TrainStep(model, criterion, opt, averager=averager, use_graph=not args.no_graph)
 
-    for _ in range(args.warmup):
+    def step():
+        return train_step(x, y)
+
+    for _ in range(max(args.warmup, 2 if train_step.use_graph else 0)):   # eager step, then capture + first replay
         step()
     # Python's generation-2 collector walks every live object (modules, parameters, autograd graph) and costs ~70 ms
     # when it triggers -- two steps' worth at local batch 32.  Move what exists now to the permanent generation so that
@@ -272,7 +271,10 @@ def main():
               key=lambda m: m.in_channels * m.out_channels * m.kernel_size[0] * m.kernel_size[1] *
               (1 if m.kernel_size[0] == 15 else 0))
     dkey = (dom.in_channels, dom.out_channels, dom.kernel_size)
-    ops.set_kernel_probe(lambda k, kind: kind == "fwd" and (k[1], k[4], (k[5], k[6])) == dkey)
+    probe = lambda k, kind: kind == "fwd" and (k[1], k[4], (k[5], k[6])) == dkey
+    graphed = train_step.graph is not None
+    if not graphed:          # kernel-by-kernel launches: HIP events bracket the dominant kernel inside the timed region
+        ops.set_kernel_probe(probe)
 
     if world > 1:
         dist.barrier()
@@ -288,6 +290,12 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if graphed:
+        # a replayed graph cannot carry timing events around one of its kernels: the same launch (same tensors, same
+        # plan) is timed right after the timed region in PROBE_STEPS kernel-by-kernel steps
+        ops.set_kernel_probe(probe)
+        for _ in range(PROBE_STEPS):
+            train_step.eager(x, y)
     probe_ms = ops.probe_results_ms()
     ops.set_kernel_probe(None)
     # which device every rank actually ran on (gathered, so the line proves N distinct GPUs took part)
@@ -330,7 +338,10 @@ def main():
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                          "kernel": f"conv_fwd_kernel {dom.in_channels}->{dom.out_channels} 15x15 @{H}x{W} "
                                    f"(upconv4.double_conv.4), local batch {B_loc}", "launch_ms": kms,
-                         "launches_timed": len(probe_ms), "algorithmic_gflop_per_launch": kflops / 1e9},
+                         "launches_timed": len(probe_ms), "algorithmic_gflop_per_launch": kflops / 1e9,
+                         "timed_in": "kernel-by-kernel steps right after the timed graph replays" if graphed
+                                     else "the timed region"},
+            "hip_graph": graphed,
         }
         if args.config in TRAIN_GFLOP_PER_PATCH and args.frames == 75:     # the FLOP table is for T = 75 patches
             step_tflops = TRAIN_GFLOP_PER_PATCH[args.config] * patches_per_s / 1e3

@@ -114,7 +114,14 @@ int mpa_upcat_bwd(const float* dout, float* dx1, float* dskip, int B, int C1, in
  * nn.LeakyReLU / nn.ReLU / nn.Sigmoid / nn.Dropout / residual adds                                         */
 int mpa_act_fwd(const float* x, float* y, int64_t n, int act, float slope, void* stream);
 int mpa_act_bwd(const float* dy, const float* x, float* dx, int64_t n, int act, float slope, void* stream);
-int mpa_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
+/* rng_state (device memory): [0] seed, [1] base offset of the current training step; `offset` = position of this call's
+ * elements inside the step.  Element i draws from the counter-based stream at rng_state[1] + offset + i.        */
+int mpa_dropout(const float* x, float* y, int64_t n, float p, const uint64_t* rng_state, uint64_t offset, void* stream);
+/* table[i] = host_ptrs[i], i < n: device pointer table written by kernels whose arguments carry the pointers (no
+ * memcpy, nothing for the host to keep alive; capturable in a HIP graph)                                       */
+int mpa_store_ptrs(const void** table, const void* const* host_ptrs, int n, void* stream);
+/* counter[0] += delta on the device (end-of-step advance of the dropout stream; capturable in a HIP graph)      */
+int mpa_u64_add(uint64_t* counter, uint64_t delta, void* stream);
 int mpa_add(const float* a, const float* b, float* y, int64_t n, void* stream);
 int mpa_axpy(float alpha, const float* x, float* y, int64_t n, void* stream);           /* y += alpha*x */
 int mpa_scale(float alpha, float* x, int64_t n, void* stream);
@@ -161,10 +168,13 @@ int mpa_ce_fwd_bwd(const float* logits, const int64_t* target, float* loss_out, 
                    float scale, void* stream);
 
 /* ------------------------------------------------------------------ AdamW (exp126a...py:103-108,293)
- * multi-tensor step: tensor lists as device-resident pointer tables.                                          */
+ * multi-tensor step: tensor lists as device-resident pointer tables.  `hyper` is device memory, double[4]:
+ * [0] learning rate (written by the host / ReduceLROnPlateau), [1] steps taken so far (the call increments it),
+ * [2],[3] scratch for the bias corrections -- nothing that changes from step to step is a kernel argument, so the
+ * call can be captured once in a HIP graph and replayed.                                                      */
 int mpa_adamw_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
-                   const int64_t* sizes, int ntensors, int64_t max_size, double lr, double beta1, double beta2,
-                   double eps, double weight_decay, int step, void* stream);
+                   const int64_t* sizes, int ntensors, int64_t max_size, double* hyper, double beta1, double beta2,
+                   double eps, double weight_decay, void* stream);
 
 /* ------------------------------------------------------------------ patch extraction + augmentation
  * replaces libdl/data_loaders/hcqt_datasets.py:67-141 (dataset_context.__getitem__) and :199-289

@@ -67,7 +67,9 @@ SIGNATURES = {
     "mpa_upcat_bwd": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P]),
     "mpa_act_fwd": (c_int, [_P, _P, c_int64, c_int, c_float, _P]),
     "mpa_act_bwd": (c_int, [_P, _P, _P, c_int64, c_int, c_float, _P]),
-    "mpa_dropout": (c_int, [_P, _P, c_int64, c_float, c_uint64, c_uint64, _P]),
+    "mpa_dropout": (c_int, [_P, _P, c_int64, c_float, _P, c_uint64, _P]),
+    "mpa_u64_add": (c_int, [_P, c_uint64, _P]),
+    "mpa_store_ptrs": (c_int, [_P, _P, c_int, _P]),
     "mpa_add": (c_int, [_P, _P, _P, c_int64, _P]),
     "mpa_axpy": (c_int, [c_float, _P, _P, c_int64, _P]),
     "mpa_scale": (c_int, [c_float, _P, c_int64, _P]),
@@ -87,7 +89,7 @@ SIGNATURES = {
     "mpa_context_batch": (c_int, [ctypes.POINTER(ContextDesc), c_int, _P, _P, _P, _P, _P, _P, _P, ctypes.c_uint64, _P, _P, _P]),
     "mpa_eval_measures_workspace": (c_int64, [c_int64, c_int]),
     "mpa_eval_measures": (c_int, [_P, _P, c_int64, c_int, c_double, _P, _P, c_int64, _P]),
-    "mpa_adamw_step": (c_int, [_P, _P, _P, _P, _P, c_int, c_int64, c_double, c_double, c_double, c_double, c_double, c_int, _P]),
+    "mpa_adamw_step": (c_int, [_P, _P, _P, _P, _P, c_int, c_int64, _P, c_double, c_double, c_double, c_double, _P]),
 }
 
 _lib = None

@@ -1841,8 +1841,7 @@ static int conv_fwd_impl(int B, int Cin, int H, int W, int Cout, int kh, int kw,
   p.coTiles = pl.coTiles; p.nTilesAll = B * pl.tilesY * pl.tilesX;
   if (mpa_cdiv(pl.nChunks, p.chunksPer) <= 1) return launch_fwd(pl, p, s);
   // channel-split launch: slices add into a zeroed output, the activation (if any) runs afterwards in place
-  (void)hipGetLastError();
-  if (hipMemsetAsync(y, 0, sizeof(float) * (size_t)B * (size_t)outBS, s) != hipSuccess) return MPA_ERR_LAUNCH;
+  if (mpa_zero_async(y, sizeof(float) * (size_t)B * (size_t)outBS, s) != MPA_OK) return MPA_ERR_LAUNCH;
   p.act = MPA_ACT_NONE;
   const int rc = launch_fwd(pl, p, s);
   if (rc != MPA_OK || act == MPA_ACT_NONE) return rc;

@@ -301,8 +301,7 @@ extern "C" int mpa_gemm(const float* A, int64_t lda_m, int64_t lda_k, const floa
     p.kchunk = (int)(mpa_cdiv(mpa_cdiv(K, splits), BK) * BK);
     splits = (int)mpa_cdiv(K, p.kchunk);
     if (!accumulate) {
-      if (ldc == N) { if (hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, s) != hipSuccess) return MPA_ERR_LAUNCH; }
-      else if (hipMemset2DAsync(C, sizeof(float) * ldc, 0, sizeof(float) * N, M, s) != hipSuccess) return MPA_ERR_LAUNCH;
+      if (mpa_zero2d_async(C, sizeof(float) * ldc, sizeof(float) * N, M, s) != MPA_OK) return MPA_ERR_LAUNCH;
     }
   }
   switch (variant) {

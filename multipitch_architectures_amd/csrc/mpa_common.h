@@ -23,6 +23,14 @@ static inline int mpa_launch_status() {
 
 static inline int64_t mpa_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Zero-fill as an ordinary kernel (rows x row_words 4-byte words, row pitch in words).  Used instead of
+// hipMemsetAsync / hipMemset2DAsync everywhere: memset *nodes* inside a captured HIP graph were replayed out of order
+// on ROCm 7.2 whenever the stream had seen an un-synchronised kernel before the graph launch (deterministic garbage in
+// the split-K accumulators); a kernel node is ordered like every other kernel of the graph.
+__global__ void mpa_zero_kernel(uint32_t* __restrict__ p, long rows, long row_words, long pitch_words);
+int mpa_zero_async(void* ptr, size_t bytes, hipStream_t s);
+int mpa_zero2d_async(void* ptr, size_t pitch_bytes, size_t width_bytes, size_t rows, hipStream_t s);
+
 __device__ __forceinline__ float mpa_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

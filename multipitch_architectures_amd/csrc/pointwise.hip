@@ -3,6 +3,24 @@
 #include "mpa_common.h"
 #include <algorithm>
 
+__global__ __launch_bounds__(256) void mpa_zero_kernel(uint32_t* __restrict__ p, long rows, long row_words, long pitch_words) {
+  const long n = rows * row_words;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long r = i / row_words, c = i - r * row_words;
+    p[r * pitch_words + c] = 0u;
+  }
+}
+int mpa_zero2d_async(void* ptr, size_t pitch_bytes, size_t width_bytes, size_t rows, hipStream_t s) {
+  if ((pitch_bytes | width_bytes | (size_t)(uintptr_t)ptr) & 3) return MPA_ERR_ARG;
+  if (!width_bytes || !rows) return MPA_OK;
+  const long n = (long)(rows * (width_bytes / 4));
+  const long blocks = n / 256 + 1 < 2048 ? n / 256 + 1 : 2048;
+  MPA_LAUNCH(mpa_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (uint32_t*)ptr, (long)rows, (long)(width_bytes / 4),
+             (long)(pitch_bytes / 4));
+  return mpa_launch_status();
+}
+int mpa_zero_async(void* ptr, size_t bytes, hipStream_t s) { return mpa_zero2d_async(ptr, bytes, bytes, 1, s); }
+
 namespace {
 
 inline unsigned blocks_for(long n, int per = 256) {
@@ -45,8 +63,12 @@ __device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t idx) {
   return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
 
+// rng_state (device): [0] seed, [1] base offset of the current step; `offset` is the call's position inside the step.
+// Both live on the device so that a captured HIP graph of the training step draws fresh masks at every replay
+// (mpa_u64_add advances the base at the end of the step).
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float p,
-                                                      float scale, uint64_t seed, uint64_t offset) {
+                                                      float scale, const uint64_t* __restrict__ rng_state, uint64_t local) {
+  const uint64_t seed = rng_state[0], offset = rng_state[1] + local;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float u = rng_uniform(seed, offset + (uint64_t)i);
     y[i] = u >= p ? x[i] * scale : 0.f;
@@ -249,11 +271,35 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restr
   }
 }
 
+// pointer table upload without a memcpy: up to 64 pointers travel as kernel arguments (copied at launch time, so the
+// host array may be reused immediately, and a captured graph replays them as constants)
+struct PtrChunk { const void* p[64]; };
+__global__ void store_ptrs_kernel(const void** __restrict__ table, PtrChunk c, int n) {
+  if ((int)threadIdx.x < n) table[threadIdx.x] = c.p[threadIdx.x];
+}
+
+__global__ void u64_add_kernel(uint64_t* __restrict__ p, uint64_t delta) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) p[0] += delta;
+}
+
 // ------------------------------------------------------------------ AdamW (multi-tensor)
+// hyper (device, float64): [0] learning rate, [1] number of steps taken, [2] 1 - beta1^step, [3] sqrt(1 - beta2^step).
+// Device-resident so that the step can sit inside a captured HIP graph: ReduceLROnPlateau writes hyper[0],
+// adamw_advance_kernel counts the step and refreshes the bias corrections (in double, as torch.optim.AdamW does on the
+// host) right before the update kernel reads them.
+__global__ void adamw_advance_kernel(double* __restrict__ hyper, double beta1, double beta2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const double step = hyper[1] + 1.0;
+    hyper[1] = step;
+    hyper[2] = 1.0 - pow(beta1, step);
+    hyper[3] = sqrt(1.0 - pow(beta2, step));
+  }
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(float* const* __restrict__ params, const float* const* __restrict__ grads,
                                                     float* const* __restrict__ m_, float* const* __restrict__ v_,
-                                                    const int64_t* __restrict__ sizes, float lr, float b1, float b2,
-                                                    float eps, float wd, float bc1, float bc2_sqrt) {
+                                                    const int64_t* __restrict__ sizes, const double* __restrict__ hyper,
+                                                    float b1, float b2, float eps, float wd) {
   const int t = blockIdx.y;
   const long n = sizes[t];
   float* p = params[t];
@@ -261,6 +307,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* const* __restrict__ p
   float* m = m_[t];
   float* v = v_[t];
   if (!g) return;
+  const float lr = (float)hyper[0], bc1 = (float)hyper[2], bc2_sqrt = (float)hyper[3];
   const float step_size = lr / bc1;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float gi = g[i];
@@ -301,11 +348,28 @@ int mpa_act_bwd(const float* dy, const float* x, float* dx, int64_t n, int act, 
   MPA_LAUNCH(act_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, dy, x, dx, (long)n, act, slope);
   return mpa_launch_status();
 }
-int mpa_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream) {
-  if (!x || !y || p < 0.f || p >= 1.f) return MPA_ERR_ARG;
+int mpa_dropout(const float* x, float* y, int64_t n, float p, const uint64_t* rng_state, uint64_t offset, void* stream) {
+  if (!x || !y || !rng_state || p < 0.f || p >= 1.f) return MPA_ERR_ARG;
   if (n == 0) return MPA_OK;
   MPA_LAUNCH(dropout_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, (long)n, p, 1.f / (1.f - p),
-                     seed, offset);
+                     rng_state, offset);
+  return mpa_launch_status();
+}
+int mpa_store_ptrs(const void** table, const void* const* host_ptrs, int n, void* stream) {
+  if (!table || !host_ptrs || n < 0) return MPA_ERR_ARG;
+  for (int o = 0; o < n; o += 64) {
+    PtrChunk c{};
+    const int m = n - o < 64 ? n - o : 64;
+    for (int i = 0; i < m; ++i) c.p[i] = host_ptrs[o + i];
+    MPA_LAUNCH(store_ptrs_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, table + o, c, m);
+    const int rc = mpa_launch_status();
+    if (rc) return rc;
+  }
+  return MPA_OK;
+}
+int mpa_u64_add(uint64_t* counter, uint64_t delta, void* stream) {
+  if (!counter) return MPA_ERR_ARG;
+  MPA_LAUNCH(u64_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, delta);
   return mpa_launch_status();
 }
 int mpa_add(const float* a, const float* b, float* y, int64_t n, void* stream) {
@@ -347,7 +411,7 @@ int mpa_channel_sum(const float* x, float* out, int B, int C, int HW, void* stre
 int mpa_colsum(const float* x, float* out, int64_t rows, int N, int accumulate, void* stream) {
   if (!x || !out) return MPA_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s) != hipSuccess) return MPA_ERR_LAUNCH;
+  if (!accumulate && mpa_zero_async(out, sizeof(float) * (size_t)N, s) != MPA_OK) return MPA_ERR_LAUNCH;
   const long colblocks = mpa_cdiv(N, 64);
   long splits = std::max<long>(1, std::min<long>(mpa_cdiv(rows, 64), mpa_cdiv(1024, colblocks)));
   MPA_LAUNCH(colsum_kernel, dim3((unsigned)colblocks, (unsigned)splits), dim3(256), 0, s, x, out, (long)rows, N);
@@ -396,14 +460,15 @@ int mpa_lstm_cell_bwd(const float* dh, int64_t dh_stride, const float* dh_rec, c
 }
 
 int mpa_adamw_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
-                   const int64_t* sizes, int ntensors, int64_t max_size, double lr, double beta1, double beta2, double eps,
-                   double weight_decay, int step, void* stream) {
-  if (!params || !grads || !exp_avg || !exp_avg_sq || !sizes || ntensors <= 0 || step <= 0) return MPA_ERR_ARG;
-  const double bc1 = 1.0 - pow(beta1, (double)step);
-  const double bc2 = 1.0 - pow(beta2, (double)step);
+                   const int64_t* sizes, int ntensors, int64_t max_size, double* hyper, double beta1, double beta2, double eps,
+                   double weight_decay, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !sizes || !hyper || ntensors <= 0 || max_size <= 0) return MPA_ERR_ARG;
+  MPA_LAUNCH(adamw_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, hyper, beta1, beta2);
+  int rc = mpa_launch_status();
+  if (rc) return rc;
   dim3 grid((unsigned)std::max<long>(1, std::min<long>(mpa_cdiv(max_size, 1024), 512)), (unsigned)ntensors);
-  MPA_LAUNCH(adamw_kernel, grid, dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, sizes, (float)lr,
-                     (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)bc1, (float)sqrt(bc2));
+  MPA_LAUNCH(adamw_kernel, grid, dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, sizes,
+             (const double*)hyper, (float)beta1, (float)beta2, (float)eps, (float)weight_decay);
   return mpa_launch_status();
 }
 

@@ -59,13 +59,39 @@ def bump_param_epoch():
 
 
 class _Rng:
+    """Counter-based dropout stream.  Element i of a dropout call draws from position base + local + i of the stream
+    `seed`; seed and base live in device memory (so a captured HIP graph of the training step draws fresh masks at every
+    replay), `local` is the call's position inside the current step and is a plain kernel argument."""
     seed = 0x5EED
-    offset = 0
+    local = 0            # elements drawn since the last rng_advance() (host mirror; static inside a captured step)
+    state = {}           # device -> int64[2] tensor: [seed, base]
 
 
 def manual_seed(seed: int):
     _Rng.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
-    _Rng.offset = 0
+    _Rng.local = 0
+    _Rng.state.clear()
+
+
+def _rng_state(device):
+    st = _Rng.state.get(device)
+    if st is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the dropout stream state must exist before a HIP graph is captured: run one eager "
+                               "(warm-up) step first")
+        seed = _Rng.seed - (1 << 64) if _Rng.seed >= (1 << 63) else _Rng.seed
+        st = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+        _Rng.state[device] = st
+    return st
+
+
+def rng_advance():
+    """End of a training step: move the device-side base of the dropout stream past everything the step drew.  One tiny
+    kernel; inside a captured graph it is what makes every replay use new random numbers."""
+    if _Rng.local:
+        for st in _Rng.state.values():
+            _chk(_lib().mpa_u64_add(ctypes.c_void_p(st.data_ptr() + 8), _Rng.local, _s()), "mpa_u64_add")
+    _Rng.local = 0
 
 
 def _packed(weight, desc, mode):
@@ -393,22 +419,23 @@ def activation(x, act, slope=0.0):
 
 
 class DropoutFn(torch.autograd.Function):
-    """nn.Dropout: Bernoulli keep mask scaled by 1/(1-p); the mask is regenerated from (seed, offset) in backward."""
+    """nn.Dropout: Bernoulli keep mask scaled by 1/(1-p); the mask is regenerated from (seed, base + offset) in backward."""
 
     @staticmethod
     def forward(ctx, x, p):
         x = _c(x)
         y = torch.empty_like(x)
-        ctx.p, ctx.seed, ctx.offset = float(p), _Rng.seed, _Rng.offset
-        _Rng.offset += x.numel()
-        _chk(_lib().mpa_dropout(_p(x), _p(y), x.numel(), ctx.p, ctx.seed, ctx.offset, _s()), "mpa_dropout")
+        ctx.p, ctx.state, ctx.offset = float(p), _rng_state(x.device), _Rng.local
+        _Rng.local += x.numel()
+        _chk(_lib().mpa_dropout(_p(x), _p(y), x.numel(), ctx.p, _p(ctx.state), ctx.offset, _s()), "mpa_dropout")
         return y
 
     @staticmethod
     def backward(ctx, dy):
         dy = _c(dy)
         dx = torch.empty_like(dy)
-        _chk(_lib().mpa_dropout(_p(dy), _p(dx), dy.numel(), ctx.p, ctx.seed, ctx.offset, _s()), "mpa_dropout")
+        # same (seed, base + offset) as the forward: the base only moves in rng_advance(), after the step's backward
+        _chk(_lib().mpa_dropout(_p(dy), _p(dx), dy.numel(), ctx.p, _p(ctx.state), ctx.offset, _s()), "mpa_dropout")
         return dx, None
 
 

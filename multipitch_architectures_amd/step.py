@@ -1,0 +1,85 @@
+"""One training step -- forward, loss, backward, (gradient averaging,) AdamW -- as a replayable HIP graph.
+
+The reference's loop body (exp126a_musicnet_cnn_basic.py:318-327)
+
+    y_pred = model(local_batch); loss = criterion(y_pred, local_labels)
+    optimizer.zero_grad(); loss.backward(); optimizer.step()
+
+is ~520 kernel launches for SAUnet:L.  At the local batch of an 8-GPU run (32 patches) the kernels take ~30 ms and the
+launch-to-launch gaps another ~1.3 ms; replaying the captured step removes the host from the loop entirely.  Everything
+that varies between steps is device-resident (dropout stream position, AdamW step count and learning rate, BatchNorm
+running statistics), so one capture serves the whole run.
+
+    step = TrainStep(model, criterion, optimizer)        # criterion(model_output, y) -> scalar loss
+    for x, y in loader:
+        loss = step(x, y)                                 # static tensor; float(loss) syncs, as loss.item() does
+
+Batches whose shape differs from the captured one (the last, smaller batch of an epoch) run eagerly.
+"""
+import torch
+
+from . import ops
+
+
+class TrainStep:
+    def __init__(self, model, criterion, optimizer, averager=None, use_graph=True):
+        self.model, self.criterion, self.opt, self.averager = model, criterion, optimizer, averager
+        # collectives stay outside captured graphs (see parallel.py): with an averager the step runs eagerly
+        self.use_graph = bool(use_graph) and averager is None
+        self.graph = None
+        self.shape = None            # shapes the graph was captured for
+        self._eager_shape = None     # shapes of the last eager step (the capture follows an eager step of its shape)
+        self._x = self._y = self._loss = None
+        self.replays = 0
+
+    # the loop body, launched kernel by kernel
+    def eager(self, x, y):
+        loss = self.criterion(self.model(x), y)
+        self.opt.zero_grad()
+        loss.backward()
+        if self.averager is not None:
+            self.averager.finish()
+        self.opt.step()
+        ops.rng_advance()
+        # detached: a caller holding the loss across iterations (every training loop does) must not keep this step's
+        # autograd nodes alive -- stale AccumulateGrad nodes would run on the stream they were created on and break the
+        # capture of the next step
+        return loss.detach()
+
+    def _capture(self, x, y):
+        # No throw-away warm-up steps (they would be extra optimiser steps the reference's loop does not take): the
+        # capture is taken on the second step of a shape, after an ordinary eager step has created everything that is
+        # set up lazily -- optimizer state, the dropout stream state, kernel attributes.
+        self._x, self._y = x.clone(), y.clone()
+        self.opt.sync_hyper()
+        self.opt.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._loss = self.eager(self._x, self._y)
+        self.graph, self.shape = graph, (tuple(x.shape), tuple(y.shape))
+
+    def __call__(self, x, y):
+        if not self.use_graph:
+            return self.eager(x, y)
+        shape = (tuple(x.shape), tuple(y.shape))
+        if self.graph is None:
+            if shape != self._eager_shape or not self.model.training:
+                self._eager_shape = shape
+                return self.eager(x, y)
+            self._capture(x, y)
+        if shape != self.shape:
+            return self.eager(x, y)
+        if x.data_ptr() != self._x.data_ptr():
+            self._x.copy_(x)
+        if y.data_ptr() != self._y.data_ptr():
+            self._y.copy_(y)
+        self.opt.sync_hyper()                        # ReduceLROnPlateau may have changed the learning rate
+        self.graph.replay()
+        self.replays += 1
+        self.opt.note_steps(1)                       # host mirrors of what the graph did on the device
+        ops.bump_param_epoch()
+        return self._loss
+
+    def static_inputs(self):
+        """the graph's input tensors: fill them in place to skip the copy in __call__"""
+        return self._x, self._y

@@ -1,0 +1,121 @@
+"""The captured training step (step.TrainStep: forward + loss + backward + AdamW as one HIP graph) against the same loop
+body launched kernel by kernel.  What must hold for the graph to be a drop-in for the reference's loop
+(exp126a_musicnet_cnn_basic.py:318-327): fresh dropout masks at every replay, the AdamW bias correction advancing, a
+learning-rate change by ReduceLROnPlateau reaching the replayed kernels, odd-sized batches still working."""
+import numpy as np
+import pytest
+import torch
+
+from multipitch_architectures_amd import nn_models, ops
+from multipitch_architectures_amd.configs import CONFIGS
+from multipitch_architectures_amd.losses import BCELoss, PolyphonyLoss
+from multipitch_architectures_amd.optim import AdamW
+from multipitch_architectures_amd.step import TrainStep
+from multipitch_architectures_amd.synth import det_fill, synth_batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _run(dev, name, use_graph, steps, lr=1e-3, B=6, lr_after=None, batches=None):
+    cfg = CONFIGS[name]
+    model = getattr(nn_models, cfg["cls"])(**cfg["kwargs"])
+    model.load_state_dict(det_fill(model.state_dict()))
+    model.to(dev).train()
+    ops.manual_seed(77)
+    is_p = cfg["cls"].endswith("polyphony_classif_softmax")
+    pl, bce = PolyphonyLoss(), BCELoss()
+    crit = (lambda r, t: pl(r[0], r[1], t)) if is_p else bce
+    opt = AdamW(model.parameters(), lr=lr)
+    ts = TrainStep(model, crit, opt, use_graph=use_graph)
+    losses = []
+    for i in range(steps):
+        if lr_after is not None and i == lr_after[0]:
+            opt.param_groups[0]["lr"] = lr_after[1]                    # what ReduceLROnPlateau does
+        x, y = synth_batch(B if batches is None else batches[i], 75, seed=100 + (i % 2))
+        losses.append(float(ts(x.to(dev), y.to(dev)).detach()))
+    return losses, [p.detach().cpu() for p in model.parameters()], ts, opt
+
+
+def test_graph_replays_match_the_eager_loop(dev):
+    """tiny:CNN (dropout, no BatchNorm -- not chaotic): same seeds, 6 steps on alternating batches"""
+    le, pe, _, _ = _run(dev, "tiny:CNN", False, 6)
+    lg, pg, ts, opt = _run(dev, "tiny:CNN", True, 6)
+    assert ts.graph is not None and ts.replays == 5                 # step 0 eager, capture at step 1, replays 1..5
+    np.testing.assert_allclose(lg, le, rtol=3e-4)
+    for a, b in zip(pg, pe):
+        assert float((a - b).abs().max()) <= 3e-4 * max(float(b.abs().max()), 1e-3)
+    assert all(st["step"] == 6 for st in opt.state.values())
+
+
+def test_replays_draw_fresh_dropout_masks_and_follow_the_same_stream(dev):
+    """lr = 0: parameters never move, so on a repeated batch the loss changes only through the dropout masks"""
+    le, _, _, _ = _run(dev, "tiny:CNN", False, 5, lr=0.0, batches=[4] * 5)
+    lg, _, ts, _ = _run(dev, "tiny:CNN", True, 5, lr=0.0, batches=[4] * 5)
+    assert ts.replays == 4
+    # the two batches alternate: steps 0,2,4 see one batch, 1,3 the other -- same data, different masks
+    assert len({round(v, 7) for v in (lg[0], lg[2], lg[4])}) == 3
+    np.testing.assert_allclose(lg, le, rtol=1e-6)
+
+
+def test_learning_rate_change_reaches_the_replayed_update(dev):
+    le, pe, _, _ = _run(dev, "tiny:CNN", False, 6, lr_after=(3, 1e-4))
+    lg, pg, ts, _ = _run(dev, "tiny:CNN", True, 6, lr_after=(3, 1e-4))
+    l_const, _, _, _ = _run(dev, "tiny:CNN", True, 6)
+    # (backward-data launches of small grids add channel slices atomically: runs agree to rounding, not bit for bit)
+    np.testing.assert_allclose(lg, le, rtol=3e-4)
+    assert abs(lg[5] - l_const[5]) > 10 * abs(lg[5] - le[5])         # the change did something, well above that noise
+    for a, b in zip(pg, pe):
+        assert float((a - b).abs().max()) <= 3e-4 * max(float(b.abs().max()), 1e-3)
+
+
+def test_kernels_launched_between_replays_do_not_disturb_the_graph(dev):
+    """Regression: with hipMemsetAsync *nodes* in the captured step (split-K accumulators, BatchNorm sums) ROCm 7.2
+    replayed garbage whenever an ordinary kernel had been launched on the stream since the last host synchronisation
+    -- e.g. the patch-extraction kernel of the data loader.  The library zero-fills with kernels now; an unrelated fill
+    between two replays must change nothing."""
+    other = torch.zeros(1 << 16, device=dev)
+    ref, _, _, _ = _run(dev, "tiny:CNN", True, 6)
+
+    def poked():
+        cfg = CONFIGS["tiny:CNN"]
+        model = getattr(nn_models, cfg["cls"])(**cfg["kwargs"])
+        model.load_state_dict(det_fill(model.state_dict()))
+        model.to(dev).train()
+        ops.manual_seed(77)
+        ts = TrainStep(model, BCELoss(), AdamW(model.parameters(), lr=1e-3))
+        out = []
+        for i in range(6):
+            x, y = synth_batch(6, 75, seed=100 + (i % 2))
+            x, y = x.to(dev), y.to(dev)
+            if i >= 2:
+                other.fill_(float(i))                    # un-synchronised kernel right before the replay
+            out.append(float(ts(x, y)))
+        return out
+    np.testing.assert_allclose(poked(), ref, rtol=3e-4)
+
+
+def test_odd_batch_runs_eagerly_between_replays(dev):
+    sizes = [6, 6, 6, 3, 6]
+    le, _, _, _ = _run(dev, "tiny:CNN", False, 5, batches=sizes)
+    lg, _, ts, opt = _run(dev, "tiny:CNN", True, 5, batches=sizes)
+    assert ts.replays == 3
+    np.testing.assert_allclose(lg, le, rtol=3e-4)
+    assert all(st["step"] == 5 for st in opt.state.values())
+
+
+@pytest.mark.parametrize("name", ["tiny:SAUnet", "tiny:BLUnet", "tiny:PUnet", "tiny:DRCNN"])
+def test_every_family_captures_and_trains(dev, name):
+    """BatchNorm running statistics, batch-axis attention, the BiLSTM recurrence and the two-headed loss inside a graph"""
+    lg, pg, ts, _ = _run(dev, name, True, 6, B=4)
+    assert ts.graph is not None and ts.replays == 5
+    assert np.isfinite(lg).all() and lg[-1] < lg[0]
+    assert all(torch.isfinite(p).all() for p in pg)
+    le, _, _, _ = _run(dev, name, False, 2, B=4)
+    np.testing.assert_allclose(lg[:2], le, rtol=1e-4)               # step 1 is the first replay
