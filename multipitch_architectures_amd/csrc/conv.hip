@@ -126,7 +126,6 @@ FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
             const int regs = NB * PB * 4 + 4 * (NB + PB) + 48;
             const long bpc = std::max<long>(1, std::min<long>(std::min<long>(4, (160 * 1024) / (long)lds), 512 / regs));
             const long blocks = (long)B * ty * tx * coTiles;
-            const long rounds = mpa_cdiv(blocks, 256 * bpc);
             // cycles one workgroup needs when it shares each SIMD with bpc-1 others
             // operand term: every non-MFMA vector instruction costs ~4 of an MFMA's 32 cycles -- (NB+PB) LDS reads plus
             // their address arithmetic per NB*PB MFMAs (about half of that in the tap-vector kernels); barrier term:
@@ -136,26 +135,23 @@ FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
                                      (1.0 + 12.5 / ((double)kw * (CK / 4) * NB * PB)) * (quad ? 1.0 : 1.08);
             // large grids: throughput (blocks * per_block / 256 CUs); small grids: whole rounds
             const double fill = (double)(TH * TW) / P;      // lanes doing useful work
-            // few rounds: whole rounds are paid (measured: 3.01 rounds cost as much as 3.32); many rounds: workgroups
-            // drift apart and only ~a third of a round is lost at the end
-            const double frac_rounds = (double)blocks / (256.0 * bpc);
-            const double eff_rounds = rounds <= 3 ? (double)rounds : frac_rounds + 0.35;
-            const long occ = std::min<long>(bpc, mpa_cdiv(blocks, 256));     // workgroups actually sharing a CU
-            double cost = eff_rounds * occ * per_block * (1.0 + 0.25 * (1.0 - fill)) +
-                                1e-3 * blocks;
+            // A CU's MFMA pipes are shared by its resident workgroups, so what a launch costs is the number of
+            // workgroups the *busiest CU* has to work through: ceil(blocks / 256) tiles for small grids (704 tiles are
+            // 2.75 per CU, i.e. 3 -- measured 117 instead of 132 TFLOP/s for the 128->16 backward-data at batch 32,
+            // where 1024 smaller tiles are exactly 4 per CU), blocks / 256 plus a drifting tail for large ones.
+            const double xcu = (double)blocks / 256.0;
+            auto cu_load = [&](double x) { return x <= 3.0 * bpc ? std::ceil(x) : x + 0.35 * bpc; };
+            double cost = cu_load(xcu) * per_block * (1.0 + 0.25 * (1.0 - fill)) + 1e-3 * blocks;
             // Small grids (small batch x small image: the U-Net's deep levels): split the input channels over
             // blockIdx.z so that efficient wave tiles still fill the chip; partial sums are added atomically into a
             // zeroed output.  Each extra slice pays a prologue/epilogue (~6 % of a full-K workgroup).
             const int nChunks = (int)mpa_cdiv(Cin, CK);
             int KS = 1;
             static const int ks_max = getenv("MPA_FWD_KS_MAX") ? atoi(getenv("MPA_FWD_KS_MAX")) : 16;   // diagnostics
-            if (rounds <= 2 && allow_split) {
+            if (xcu <= 2.0 * bpc && allow_split) {
               for (int ks = 2; ks <= ks_max && ks <= nChunks; ks *= 2) {
-                const long r2 = mpa_cdiv(blocks * ks, 256 * bpc);
-                const double f2 = (double)(blocks * ks) / (256.0 * bpc);
-                const double e2 = r2 <= 3 ? (double)r2 : f2 + 0.35;
-                const long occ2 = std::min<long>(bpc, mpa_cdiv(blocks * ks, 256));
-                const double c2 = e2 * occ2 * per_block * (1.0 / ks + 0.06) * (1.0 + 0.25 * (1.0 - fill)) + 1e-3 * blocks * ks;
+                const double c2 = cu_load(xcu * ks) * per_block * (1.0 / ks + 0.06) * (1.0 + 0.25 * (1.0 - fill)) +
+                                  1e-3 * blocks * ks;
                 if (c2 < cost) { cost = c2; KS = ks; }
               }
             }

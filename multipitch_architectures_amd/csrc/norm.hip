@@ -461,20 +461,26 @@ int mpa_layernorm_cf_fwd(const float* x, const float* w, const float* b, float* 
 
 // workspace (caller-allocated, mpa_layernorm_bwd_workspace bytes): one partial dgamma/dbeta row per workgroup, reduced
 // by reduce2_kernel in a fixed order
-#define LN_BWD_BLOCKS 1024   // workgroups of the row loop (each leaves one partial dgamma/dbeta row in the workspace)
+#define LN_BWD_BLOCKS 1024   // at most this many workgroups in the row loop (each leaves one partial dgamma/dbeta row)
 int64_t mpa_layernorm_bwd_workspace(int n) { return (int64_t)LN_BWD_BLOCKS * 2 * n * 4; }
+// eight rows per wave at least: with few rows (local batch 32: 2400 rows) 1024 partial rows made the fixed-order
+// reduction of the partials cost more than the row loop itself
+static inline int ln_bwd_blocks(int64_t rows) {
+  const int64_t b = mpa_cdiv(rows, 32);
+  return (int)(b < 32 ? 32 : b > LN_BWD_BLOCKS ? LN_BWD_BLOCKS : b);
+}
 
 int mpa_layernorm_cf_bwd_ws(const float* dy, const float* x, const float* w, const float* mean, const float* rstd, float* dx,
                             float* dw, float* db, void* ws, int B, int C, int T, int F, void* stream) {
   if (!dy || !x || !w || !mean || !rstd || !dw || !db || !ws || C * F > 64 * LNCF_MAXV) return MPA_ERR_ARG;
   const int n = C * F;
   hipStream_t s = (hipStream_t)stream;
-  MPA_LAUNCH(layernorm_cf_bwd_kernel, dim3(LN_BWD_BLOCKS), dim3(256), (size_t)8 * n * 4, s, dy, x, w, mean, rstd, dx,
+  const int nb = ln_bwd_blocks((int64_t)B * T);
+  MPA_LAUNCH(layernorm_cf_bwd_kernel, dim3(nb), dim3(256), (size_t)8 * n * 4, s, dy, x, w, mean, rstd, dx,
                      (float*)ws, B, C, T, F);
   int rc = mpa_launch_status();
   if (rc) return rc;
-  MPA_LAUNCH(reduce2_kernel, dim3((unsigned)mpa_cdiv(2 * n, 64)), dim3(256), 0, s, (const float*)ws, dw, db, n,
-                     LN_BWD_BLOCKS);
+  MPA_LAUNCH(reduce2_kernel, dim3((unsigned)mpa_cdiv(2 * n, 64)), dim3(256), 0, s, (const float*)ws, dw, db, n, nb);
   return mpa_launch_status();
 }
 
@@ -490,12 +496,12 @@ int mpa_layernorm_rows_bwd_ws(const float* dy, const float* xs, const float* w, 
                               float* dx, float* dw, float* db, void* ws, int64_t rows, int E, void* stream) {
   if (!dy || !xs || !w || !mean || !rstd || !dx || !dw || !db || !ws || E > 64 * LNR_MAXV) return MPA_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  MPA_LAUNCH(layernorm_rows_bwd_kernel, dim3(LN_BWD_BLOCKS), dim3(256), (size_t)8 * E * 4, s, dy, xs, w, mean, rstd,
+  const int nb = ln_bwd_blocks(rows);
+  MPA_LAUNCH(layernorm_rows_bwd_kernel, dim3(nb), dim3(256), (size_t)8 * E * 4, s, dy, xs, w, mean, rstd,
                      dx, (float*)ws, (long)rows, E);
   int rc = mpa_launch_status();
   if (rc) return rc;
-  MPA_LAUNCH(reduce2_kernel, dim3((unsigned)mpa_cdiv(2 * E, 64)), dim3(256), 0, s, (const float*)ws, dw, db, E,
-                     LN_BWD_BLOCKS);
+  MPA_LAUNCH(reduce2_kernel, dim3((unsigned)mpa_cdiv(2 * E, 64)), dim3(256), 0, s, (const float*)ws, dw, db, E, nb);
   return mpa_launch_status();
 }
 
