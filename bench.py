@@ -199,6 +199,35 @@ def eval_measures_probe(with_cpu, n_frames=20000):
     return res
 
 
+def segment_inference_probe(model, n_frames=2000, segment=100):
+    """whole-recording inference, the reference's loop (one 75-frame patch per output frame,
+    exp126a...py:427-443) next to the opt-in segment-wise path (windows of segment+74 frames, `segment` frames per
+    forward).  Eval mode, the recording resident in HBM, predictions left on the device."""
+    from multipitch_architectures_amd import experiment
+    from multipitch_architectures_amd.synth import synth_file
+    inputs, targets = synth_file(frames=n_frames, seed=21)
+    was_training = model.training
+    model.eval()
+    res = {"frames": n_frames, "segment": segment}
+    out = {}
+    for key, seg in (("per_patch", None), ("segment_wise", segment)):
+        experiment.predict_file(model, inputs, targets, segment=seg)         # warm-up: plans, packed filters
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out[key] = experiment.predict_file(model, inputs, targets, segment=seg)
+        torch.cuda.synchronize()
+        res[key + "_frames_per_s"] = n_frames / (time.perf_counter() - t0)
+    d = (out["per_patch"] - out["segment_wise"]).abs()
+    res["speedup"] = res["segment_wise_frames_per_s"] / res["per_patch_frames_per_s"]
+    res["max_abs_diff"], res["mean_abs_diff"] = float(d.max()), float(d.mean())
+    res["note"] = ("segment-wise is an approximation of the per-patch loop (zero padding at window instead of patch "
+                   "borders); the weights are the randomly initialised ones after the timed steps, whose outputs are almost "
+                   "constant (SURVEY section 4), so the deviation printed here is not informative -- "
+                   "tests/test_gpu_experiment.py::test_segment_wise_inference exercises it with the deterministic fill")
+    model.train(was_training)
+    return res
+
+
 def main():
     args = parse_args()
 
@@ -352,6 +381,7 @@ def main():
         if world == 1:
             out["patch_extraction"] = patch_extraction_probe(B_loc, not args.no_cpu_baseline)
             out["eval_measures"] = eval_measures_probe(not args.no_cpu_baseline)
+            out["segment_inference"] = segment_inference_probe(model)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

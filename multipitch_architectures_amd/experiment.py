@@ -23,7 +23,7 @@ import torch
 
 from . import nn_models
 from .configs import CONFIGS
-from .data_loaders import ContextLoader, dataset_context
+from .data_loaders import ContextLoader, dataset_context, dataset_context_segm
 from .losses import BCELoss, PolyphonyLoss
 from .metrics import MEASURES, calculate_eval_measures
 from .metrics.eval_metrics import aggregate_files
@@ -111,26 +111,59 @@ def train(model, criterion, train_files, val_files, lr=1e-3, max_epochs=100, bat
 
 
 @torch.no_grad()
-def predict_file(model, inputs, targets, batch_size=50):
-    """frame-wise predictions of one recording, as exp180d...py:420-440: pad half a context on both sides, stride 1."""
+def predict_file(model, inputs, targets, batch_size=50, segment=None):
+    """frame-wise predictions of one recording, (T, n_out), on the device.
+
+    ``segment=None`` -- the reference's test loop (exp180d...py:420-440): pad half a context on both sides, one
+    75-frame patch per output frame (stride 1), batches of 50.
+
+    ``segment=L`` -- opt-in fast path: the padded recording is cut into windows of L + 74 frames at
+    stride L (the ``dataset_context_segm`` shape, hcqt_datasets.py:144-289) and every forward pass writes L output
+    frames: L x less convolution work per frame for the large layers.  The models are fully convolutional in time
+    (T >= 75 in, T - 74 out), so this runs the same kernels; it is *not* bit-identical to the per-patch loop for any
+    family: a 75-frame patch zero-pads the 15x15 / 3x3 convolutions and the time pools at *its own* borders, a long
+    window only at the window's (and the U-Nets additionally align their 2x2 pooling grid to the window start).  What
+    holds exactly: ``segment=1`` is the per-patch loop, and window k of the result is ``model(window k)``.  The
+    deviation from the per-patch predictions is reported by ``bench.py`` (``segment_inference``).  Models with the
+    batch-axis attention (SAUnet / SAUSnet) mix the windows of a batch exactly as they mix the patches of a batch."""
     half = TEST_DATASET_PARAMS["context"] // 2
     inputs = np.pad(np.asarray(inputs), ((0, 0), (half, half + 1), (0, 0)))
     targets_p = np.pad(np.asarray(targets), ((half, half + 1), (0, 0)))
-    ds = dataset_context(inputs, targets_p, dict(TEST_DATASET_PARAMS))
+    first = lambda res: res[0] if isinstance(res, tuple) else res
+    if segment is None:
+        ds = dataset_context(inputs, targets_p, dict(TEST_DATASET_PARAMS))
+        preds = []
+        for X, _ in ContextLoader([ds], batch_size, shuffle=False):
+            preds.append(first(model(X)).squeeze(2).squeeze(1))
+        return torch.cat(preds)                      # (T, n_out), stays on the device
+    L = int(segment)
+    if L < 1:
+        raise ValueError("segment must be a positive number of frames")
+    T = inputs.shape[1] - 2 * half - 1               # frames of the recording = frames to predict
+    n_full, rem = divmod(T, L)
     preds = []
-    for X, _ in ContextLoader([ds], batch_size, shuffle=False):
-        res = model(X)
-        y = res[0] if isinstance(res, tuple) else res
-        preds.append(y.squeeze(2).squeeze(1))
-    return torch.cat(preds)                      # (T, n_out), stays on the device
+    if n_full:
+        ds = dataset_context_segm(inputs, targets_p, dict(TEST_DATASET_PARAMS, seglength=L, stride=L))
+        per_batch = max(1, (batch_size * 75) // (L + 74))     # about as many input frames per forward as the patch loop
+        for i in range(0, n_full, per_batch):
+            X, _ = ds.batch(list(range(i, min(i + per_batch, n_full))))
+            y = first(model(X))                      # (b, 1, L, n_out)
+            preds.append(y.squeeze(1).reshape(-1, y.shape[-1]))
+    if rem:                                          # the last, shorter window: rem + 74 frames -> rem frames
+        tail = inputs[:, n_full * L:, :]
+        ds = dataset_context_segm(tail, targets_p[n_full * L:], dict(TEST_DATASET_PARAMS, seglength=rem, stride=rem))
+        X, _ = ds.batch([0])
+        y = first(model(X))
+        preds.append(y.squeeze(1).reshape(-1, y.shape[-1]))
+    return torch.cat(preds)
 
 
-def test(model, test_files, names=None, measures=MEASURES, log=logging.info):
+def test(model, test_files, names=None, measures=MEASURES, log=logging.info, segment=None):
     log("\n \n ###################### START TESTING ###################### \n")
     model.eval()
     per_file, n_frames = [], []
     for k, (inputs, targets) in enumerate(test_files):
-        pred = predict_file(model, inputs, targets)
+        pred = predict_file(model, inputs, targets, segment=segment)
         targ = torch.as_tensor(np.asarray(targets), dtype=torch.float32)
         assert tuple(pred.shape) == tuple(targ.shape), "Shape mismatch! Target shape: " + str(tuple(targ.shape)) + \
             ", Pred. shape: " + str(tuple(pred.shape))

@@ -55,3 +55,38 @@ def test_exp2_variant_uses_stride_20_and_caps_the_epoch(monkeypatch):
                             log=lambda *_: None)
     assert seen == [20, 20] and len(hist) == 2
     assert len(steps) == 2 * 4                       # 147 patches at stride 20 = 6 batches of 25 when uncapped
+
+
+@pytest.mark.parametrize("name", ["tiny:CNN", "tiny:DRCNN", "tiny:Unet"])
+def test_segment_wise_inference(name):
+    """`predict_file(segment=L)` feeds (6, L+74, 216) windows (hcqt_datasets.py:144-289 shape) instead of
+    one 75-frame patch per frame (exp126a...py:427-443).  Exact properties: segment=1 *is* the per-patch loop; window k
+    of the result is model(window k) -- including the shorter last window; the result has one row per frame.  It is an
+    approximation of the per-patch predictions (different zero-padding borders), so that deviation is only bounded
+    loosely here and reported by bench.py."""
+    from multipitch_architectures_amd import experiment, nn_models
+    from multipitch_architectures_amd.configs import CONFIGS
+    from multipitch_architectures_amd.synth import det_fill, synth_file
+    dev = torch.device("cuda:0")
+    cfg = CONFIGS[name]
+    model = getattr(nn_models, cfg["cls"])(**cfg["kwargs"])
+    model.load_state_dict(det_fill(model.state_dict()))
+    model.to(dev).eval()
+    inputs, targets = synth_file(frames=230, seed=5)
+    ref = experiment.predict_file(model, inputs, targets).cpu()                    # the reference's loop
+    assert tuple(ref.shape) == (230, 72)
+    one = experiment.predict_file(model, inputs, targets, segment=1).cpu()
+    assert float((one - ref).abs().max()) <= 1e-5
+    L = 100
+    seg = experiment.predict_file(model, inputs, targets, segment=L).cpu()         # windows 100, 100, 30
+    assert tuple(seg.shape) == (230, 72)
+    padded = np.pad(inputs, ((0, 0), (37, 38), (0, 0)))
+    with torch.no_grad():
+        for k, (s, n) in enumerate([(0, 100), (100, 100), (200, 30)]):
+            win = torch.from_numpy(np.log(1.0 + 10.0 * padded[None, :, s:s + n + 74, :]).astype(np.float32)).to(dev)
+            want = model(win).cpu()[0, 0]
+            assert float((seg[s:s + n] - want).abs().max()) <= 1e-5, k   # logf vs np.log, batch-dependent plans
+    assert float((seg - ref).abs().max()) < 0.5 and torch.isfinite(seg).all()
+    # the runner's test() accepts the switch and produces the same measures layout
+    mean, _ = experiment.test(model, [(inputs, targets)], ["f"], log=lambda *_: None, segment=L)
+    assert set(mean) == set(experiment.MEASURES)
