@@ -40,6 +40,7 @@ for _name in ("tiny:CNN", "tiny:DRCNN", "tiny:Unet", "tiny:SAUnet", "tiny:SAUnet
               "tiny:BLUnet", "tiny:PUnet"):
     CASES += [(_name, 1, 75, False), (_name, 2, 75, True), (_name, 8, 75, False), (_name, 2, 174, False)]
 CASES += [("tiny:SAUnet", 25, 75, True), ("tiny:SAUnet", 50, 75, False), ("tiny:Unet", 3, 100, True)]
+CASES += [("tiny:Unet", 32, 75, True)]      # BatchNorm over 32 patches is not chaotic: a tight whole-model gradient check
 CASES += [
     ("CNN:XS", 8, 75, True), ("CNN:XS", 8, 174, False),        # BASELINE.json configs[0]
     ("DRCNN:L", 1, 75, False),
@@ -220,7 +221,7 @@ def main():
     args = ap.parse_args()
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     for cfg_name, B, T, tr in CASES:
-        if args.only and args.only not in cfg_name:
+        if args.only and args.only not in cfg_name and args.only not in os.path.basename(case_file(cfg_name, B, T)):
             continue
         out = run_case(cfg_name, B, T, tr)
         np.savez_compressed(case_file(cfg_name, B, T), **out)

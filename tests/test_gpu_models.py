@@ -140,7 +140,10 @@ def test_train_step_matches_reference_goldens(dev, case):
                     # nets amplify last-bit differences (any change of summation order moves the first layers'
                     # gradients by up to ~2 % of their largest entry -- the reference's CPU kernels sum in blocks, the
                     # MFMA path in one K-long chain)
-                    tol = 20.0 * ref_noise + 1e-2 * scale + 1e-9
+                    # With 32 patches per batch the BatchNorm statistics are stable and that amplification is gone:
+                    # there the floor is ten times tighter (tiny:Unet B32; tiny:SAUnet B25 still needs 2 % because its
+                    # batch-axis attention couples all patches).
+                    tol = 20.0 * ref_noise + (1e-2 if B < 32 else 1e-3) * scale + 1e-9
                     err = np.abs(mine - r64).max()
                 else:
                     scale = max(np.abs(r32).max(), float(g[f"grad.{k}.norm"]) / np.sqrt(p.numel()))
