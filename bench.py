@@ -295,12 +295,26 @@ def main():
     # collections inside the timed region only look at objects created by the steps themselves.
     gc.collect()
     gc.freeze()
-    # live roofline probe: the dominant kernel = the widest 15x15 forward conv (upconv4.double_conv.4: 16->128)
-    dom = max((m for m in model.modules() if isinstance(m, nn_models.layers.Conv2d)),
-              key=lambda m: m.in_channels * m.out_channels * m.kernel_size[0] * m.kernel_size[1] *
-              (1 if m.kernel_size[0] == 15 else 0))
-    dkey = (dom.in_channels, dom.out_channels, dom.kernel_size)
-    probe = lambda k, kind: kind == "fwd" and (k[1], k[4], (k[5], k[6])) == dkey
+    # live roofline probe: the dominant kernel = the forward convolution with the most algorithmic FLOPs (SAUnet:L:
+    # upconv4.double_conv.4, 16->128 15x15 @75x216, 51 % of the model's MACs); input shapes recorded by forward hooks
+    shapes = {}
+    hooks = [m.register_forward_pre_hook(lambda mod, inp, nm=nm: shapes.__setitem__(nm, (mod, tuple(inp[0].shape))))
+             for nm, m in model.named_modules() if isinstance(m, nn_models.layers.Conv2d)]
+    model.eval()                       # (in training mode double_conv calls conv.forward_stats, which bypasses hooks)
+    with torch.no_grad():
+        model(x[:1])
+    model.train()
+    for h in hooks:
+        h.remove()
+
+    def conv_flops(mod, shp):
+        oh = (shp[2] + 2 * mod.padding[0] - mod.kernel_size[0]) // mod.stride[0] + 1
+        ow = (shp[3] + 2 * mod.padding[1] - mod.kernel_size[1]) // mod.stride[1] + 1
+        return 2.0 * mod.out_channels * mod.in_channels * mod.kernel_size[0] * mod.kernel_size[1] * oh * ow, oh, ow
+    dom_name, (dom, dshape) = max(shapes.items(), key=lambda kv: conv_flops(*kv[1])[0])
+    dflops, dOH, dOW = conv_flops(dom, dshape)
+    dkey = (dom.in_channels, dshape[2], dshape[3], dom.out_channels, dom.kernel_size[0], dom.kernel_size[1])
+    probe = lambda k, kind: kind == "fwd" and tuple(k[1:7]) == dkey
     graphed = train_step.graph is not None
     if not graphed:          # kernel-by-kernel launches: HIP events bracket the dominant kernel inside the timed region
         ops.set_kernel_probe(probe)
@@ -340,8 +354,8 @@ def main():
         patches_per_s = args.global_batch / (dt / args.steps)
         frames_per_s = patches_per_s * (args.frames - 74)
         B_loc = hi - lo
-        H, W = args.frames, 216
-        kflops = 2.0 * B_loc * dom.out_channels * dom.in_channels * dom.kernel_size[0] * dom.kernel_size[1] * H * W
+        H, W = dshape[2], dshape[3]
+        kflops = dflops * B_loc
         kms = sum(probe_ms) / max(len(probe_ms), 1)
         # HBM bytes per launch of that kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/);
         # only valid for the configuration it was collected on
@@ -365,8 +379,9 @@ def main():
                        "frames": args.frames, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                         "kernel": f"conv_fwd_kernel {dom.in_channels}->{dom.out_channels} 15x15 @{H}x{W} "
-                                   f"(upconv4.double_conv.4), local batch {B_loc}", "launch_ms": kms,
+                         "kernel": f"conv_fwd_kernel {dom.in_channels}->{dom.out_channels} "
+                                   f"{dom.kernel_size[0]}x{dom.kernel_size[1]} @{H}x{W} ({dom_name}), local batch {B_loc}",
+                         "launch_ms": kms,
                          "launches_timed": len(probe_ms), "algorithmic_gflop_per_launch": kflops / 1e9,
                          "timed_in": "kernel-by-kernel steps right after the timed graph replays" if graphed
                                      else "the timed region"},

@@ -55,6 +55,13 @@ int mpa_conv2d_pack(const mpa_conv_desc* d, int mode, const float* w, float* w_p
 /* y = act(conv(x, w) + bias) ; bias may be NULL */
 int mpa_conv2d_fwd(const mpa_conv_desc* d, const float* x, const float* w_packed, const float* bias,
                    float* y, int act, float slope, void* stream);
+/* Forward convolution in front of a BatchNorm2d (double_conv, unet_cnns.py:49-59): as mpa_conv2d_fwd without activation,
+ * and the store epilogue leaves per-(pixel tile, channel) partial sums of y and y^2 in `partials`
+ * ([mpa_conv2d_fwd_stats_rows(d)][Cout][2] floats), so that the batch statistics need no extra pass over y
+ * (mpa_bn_relu_train_fwd_partials reduces them in a fixed order, in float64).                                  */
+int64_t mpa_conv2d_fwd_stats_rows(const mpa_conv_desc* d);
+int mpa_conv2d_fwd_stats(const mpa_conv_desc* d, const float* x, const float* w_packed, const float* bias, float* y,
+                         float* partials, void* stream);
 /* dx = conv_transpose(dy, w)  (w_packed from mode 1) */
 int mpa_conv2d_bwd_data(const mpa_conv_desc* d, const float* dy, const float* w_packed, float* dx, void* stream);
 /* human-readable tiling chosen for fwd (mode 0), bwd-data (1), bwd-weight (2) -- diagnostics / DESIGN.md tables */
@@ -86,6 +93,11 @@ int mpa_bn_relu_train_fwd(const float* x, const float* gamma, const float* beta,
                           float* running_var, int64_t* num_batches_tracked /*nullable, += 1*/, float* y, float* save_mean,
                           float* save_invstd, double* stats_ws, int B, int C, int HW, float momentum, float eps, int relu,
                           void* stream);
+/* as mpa_bn_relu_train_fwd with the batch statistics taken from the producing convolution's partial sums */
+int mpa_bn_relu_train_fwd_partials(const float* x, const float* partials, int rows, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, int64_t* num_batches_tracked, float* y,
+                                   float* save_mean, float* save_invstd, int B, int C, int HW, float momentum, float eps,
+                                   int relu, void* stream);
 int mpa_bn_relu_eval_fwd(const float* x, const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float* y, float* save_mean /*nullable*/, float* save_invstd /*nullable*/,
                          int B, int C, int HW, float eps, int relu, void* stream);

@@ -49,6 +49,8 @@ SIGNATURES = {
     "mpa_conv2d_packed_floats": (c_int64, [_D, c_int]),
     "mpa_conv2d_pack": (c_int, [_D, c_int, _P, _P, _P]),
     "mpa_conv2d_fwd": (c_int, [_D, _P, _P, _P, _P, c_int, c_float, _P]),
+    "mpa_conv2d_fwd_stats_rows": (c_int64, [_D]),
+    "mpa_conv2d_fwd_stats": (c_int, [_D, _P, _P, _P, _P, _P, _P]),
     "mpa_conv2d_bwd_data": (c_int, [_D, _P, _P, _P, _P]),
     "mpa_conv2d_describe_plan": (c_int, [_D, c_int, ctypes.c_char_p, c_int]),
     "mpa_conv2d_bwd_weight_workspace": (c_int64, [_D]),
@@ -59,6 +61,7 @@ SIGNATURES = {
     "mpa_layernorm_rows_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_float, _P]),
     "mpa_layernorm_rows_bwd_ws": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, _P]),
     "mpa_bn_relu_train_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_int, _P]),
+    "mpa_bn_relu_train_fwd_partials": (c_int, [_P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_int, _P]),
     "mpa_bn_relu_eval_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P]),
     "mpa_bn_relu_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "mpa_maxpool2d_fwd": (c_int, [_P, _P, _P] + [c_int] * 10 + [_P]),

@@ -386,6 +386,7 @@ struct ConvFwdParams {
   int outYmul, outH;   // phase stores: cout' = cin*(outXmul*outYmul) + v*outXmul + q -> row oy*outYmul+v (< outH), column ox*outXmul+q
   int chunksPer;       // input-channel chunks per blockIdx.z slice (== nChunks when the channels are not split)
   int coTiles, nTilesAll;   // cout tiles; pixel tiles over the whole batch
+  float* stats;             // BatchNorm fusion: per-(pixel tile, cout) partial sums of y and y^2 -> [nTilesAll][Cout][2]
 };
 
 // The one quad per row that straddles the right limit `xend` of the readable columns is skipped by the 16-byte stager;
@@ -445,6 +446,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
   const int cot = seq % p.coTiles;
   int bid = (seq / p.coTiles) * 8 + (w & 7);
   if (bid >= p.nTilesAll) return;          // padding of the last group of 8 pixel tiles (whole workgroup)
+  const int ptile = bid;
   const int tx = bid % p.tilesX;
   bid /= p.tilesX;
   const int ty = bid % p.tilesY;
@@ -593,6 +595,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
     const int co_l = lane >> 2, quad = lane & 3;      // after the transpose: lane -> (cout row, 4-pixel group)
     const float neg_scale = p.act == MPA_ACT_NONE ? 1.f : (p.act == MPA_ACT_RELU ? 0.f : p.slope);
     float* yb = p.y + (long)b * p.outBS;
+    float ssum[NB], qsum[NB];                         // BatchNorm partials (p.stats): this lane's 4-pixel groups of cout co_l
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { ssum[nb] = 0.f; qsum[nb] = 0.f; }
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
       const int pix4 = (wave * PB + pb) * 16 + quad * 4;
@@ -610,10 +615,36 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
         const int co = cot * p.COT + nb * 16 + co_l;
         const float bs = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
         v.x += bs; v.y += bs; v.z += bs; v.w += bs;
+        if (p.stats && ok4) {                         // (act is NONE in front of a BatchNorm)
+          ssum[nb] += (v.x + v.y) + (v.z + v.w);
+          qsum[nb] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
         v.x = v.x >= 0.f ? v.x : v.x * neg_scale; v.y = v.y >= 0.f ? v.y : v.y * neg_scale;
         v.z = v.z >= 0.f ? v.z : v.z * neg_scale; v.w = v.w >= 0.f ? v.w : v.w * neg_scale;
         if (ok4 && co < p.Cout)
           *reinterpret_cast<float4*>(yb + (long)co * p.outCS + (long)oy * p.outRS + ox) = v;
+      }
+    }
+    if (p.stats) {
+      // lane quads -> one value per (wave, cout), waves -> workgroup in a fixed order, one row of partials per pixel tile
+      float* red = lds + 4 * (16 * 20);               // [wave][COT][2], behind the four transpose patches
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        float sv = ssum[nb], qv = qsum[nb];
+        sv += __shfl_xor(sv, 1, 64); qv += __shfl_xor(qv, 1, 64);
+        sv += __shfl_xor(sv, 2, 64); qv += __shfl_xor(qv, 2, 64);
+        if (quad == 0) {
+          red[(wave * p.COT + nb * 16 + co_l) * 2] = sv;
+          red[(wave * p.COT + nb * 16 + co_l) * 2 + 1] = qv;
+        }
+      }
+      __syncthreads();
+      const int co = cot * p.COT + tid;
+      if (tid < p.COT && co < p.Cout) {
+        const float s4 = (red[tid * 2] + red[(p.COT + tid) * 2]) + (red[(2 * p.COT + tid) * 2] + red[(3 * p.COT + tid) * 2]);
+        const float q4 = (red[tid * 2 + 1] + red[(p.COT + tid) * 2 + 1]) +
+                         (red[(2 * p.COT + tid) * 2 + 1] + red[(3 * p.COT + tid) * 2 + 1]);
+        *reinterpret_cast<float2*>(p.stats + ((long)ptile * p.Cout + co) * 2) = make_float2(s4, q4);
       }
     }
     return;
@@ -655,6 +686,43 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
         }
       }
       return;
+    }
+  }
+  if constexpr (!PH) {
+    if (p.stats) {
+      // BatchNorm partials from the accumulators (+ bias): lane (kq, l16) holds couts nb*16 + kq*4 + r of pixel l16 of
+      // each of its PB blocks; sum its valid pixels, then the 16 pixel lanes, then the four waves through LDS
+      __syncthreads();                                  // the main loop's LDS images are dead now
+      float* red = lds;                                 // [wave][COT][2]
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = nb * 16 + kq * 4 + r, co = cot * p.COT + col;
+          const float bs = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
+          float sv = 0.f, qv = 0.f;
+#pragma unroll
+          for (int pb = 0; pb < PB; ++pb) {
+            const int pix = (wave * PB + pb) * 16 + l16;
+            const int pc = pix < npix ? pix : 0;
+            const int py = pc / p.TW, px = pc - py * p.TW;
+            const bool ok = pix < npix && oy0 + py < p.OH && ox0 + px < p.OW;
+            const float v = acc[nb][pb][r] + bs;
+            if (ok) { sv += v; qv += v * v; }
+          }
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) { sv += __shfl_xor(sv, o, 64); qv += __shfl_xor(qv, o, 64); }
+          if (l16 == 0) { red[(wave * p.COT + col) * 2] = sv; red[(wave * p.COT + col) * 2 + 1] = qv; }
+        }
+      }
+      __syncthreads();
+      const int co = cot * p.COT + tid;
+      if (tid < p.COT && co < p.Cout) {
+        const float s4 = (red[tid * 2] + red[(p.COT + tid) * 2]) + (red[(2 * p.COT + tid) * 2] + red[(3 * p.COT + tid) * 2]);
+        const float q4 = (red[tid * 2 + 1] + red[(p.COT + tid) * 2 + 1]) +
+                         (red[(2 * p.COT + tid) * 2 + 1] + red[(3 * p.COT + tid) * 2 + 1]);
+        *reinterpret_cast<float2*>(p.stats + ((long)ptile * p.Cout + co) * 2) = make_float2(s4, q4);
+      }
     }
   }
 #pragma unroll
@@ -1816,10 +1884,14 @@ int mpa_conv2d_pack(const mpa_conv_desc* d, int mode, const float* w, float* w_p
 static int conv_fwd_impl(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
                          const float* x, const float* wp, const float* bias, float* y, int act, float slope,
                          long outBS, long outCS, int outRS, int outXmul, int outCdiv, hipStream_t s, bool allow_split = false,
-                         int Hplan = 0, int outYmul = 1, int outH = 0) {
+                         int Hplan = 0, int outYmul = 1, int outH = 0, float* stats = nullptr) {
   FwdPlan pl = plan_fwd(B, Cin, Hplan ? Hplan : H, W, Cout, kh, kw, sh, sw, ph, pw, allow_split, outCdiv < Cout,
                         outCdiv < Cout ? outXmul : 1);
   if (!pl.ok) return MPA_ERR_UNSUPPORTED;
+  if (stats) {
+    if (pl.KS > 1 || act != MPA_ACT_NONE) return MPA_ERR_UNSUPPORTED;
+    pl.lds_bytes = std::max<size_t>(pl.lds_bytes, 8192);      // the epilogue's reduction scratch (tiny tiles stage less)
+  }
   ConvFwdParams p{};
   p.x = x; p.wp = wp; p.bias = bias; p.y = y;
   p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.OH = pl.OH; p.OW = pl.OW;
@@ -1835,6 +1907,7 @@ static int conv_fwd_impl(int B, int Cin, int H, int W, int Cout, int kh, int kw,
   p.outYmul = outYmul; p.outH = outH ? outH : pl.OH;
   p.chunksPer = (int)mpa_cdiv(pl.nChunks, pl.KS);
   p.coTiles = pl.coTiles; p.nTilesAll = B * pl.tilesY * pl.tilesX;
+  p.stats = stats;
   if (mpa_cdiv(pl.nChunks, p.chunksPer) <= 1) return launch_fwd(pl, p, s);
   // channel-split launch: slices add into a zeroed output, the activation (if any) runs afterwards in place
   if (mpa_zero_async(y, sizeof(float) * (size_t)B * (size_t)outBS, s) != MPA_OK) return MPA_ERR_LAUNCH;
@@ -1851,6 +1924,23 @@ int mpa_conv2d_fwd(const mpa_conv_desc* d, const float* x, const float* w_packed
   if (OH <= 0 || OW <= 0) return MPA_ERR_ARG;
   return conv_fwd_impl(d->B, d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw, x, w_packed, bias,
                        y, act, slope, (long)d->Cout * OH * OW, (long)OH * OW, OW, 1, d->Cout, (hipStream_t)stream);
+}
+
+int64_t mpa_conv2d_fwd_stats_rows(const mpa_conv_desc* d) {
+  if (!d) return MPA_ERR_ARG;
+  FwdPlan pl = plan_fwd(d->B, d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw);
+  if (!pl.ok) return MPA_ERR_UNSUPPORTED;
+  return (int64_t)d->B * pl.tilesY * pl.tilesX;
+}
+
+int mpa_conv2d_fwd_stats(const mpa_conv_desc* d, const float* x, const float* w_packed, const float* bias, float* y,
+                         float* partials, void* stream) {
+  if (!d || !x || !w_packed || !y || !partials || d->B <= 0) return MPA_ERR_ARG;
+  const int OH = (d->H + 2 * d->ph - d->kh) / d->sh + 1, OW = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
+  if (OH <= 0 || OW <= 0) return MPA_ERR_ARG;
+  return conv_fwd_impl(d->B, d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw, x, w_packed, bias,
+                       y, MPA_ACT_NONE, 0.f, (long)d->Cout * OH * OW, (long)OH * OW, OW, 1, d->Cout, (hipStream_t)stream,
+                       false, 0, 1, 0, partials);
 }
 
 int mpa_conv2d_bwd_data(const mpa_conv_desc* d, const float* dy, const float* w_packed, float* dx, void* stream) {

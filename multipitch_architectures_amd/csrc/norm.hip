@@ -313,6 +313,67 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, float* runn
   running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
 }
 
+// Batch statistics from the per-(pixel tile, channel) partial sums the producing convolution left behind
+// (conv_fwd_kernel's epilogue): partials [rows][C][2] (sum, sum of squares; float) -> the same outputs as
+// bn_finalize_kernel.  One workgroup per 16 channels; 16 row groups accumulate in double and are combined through LDS in
+// a fixed order (run-to-run reproducible).
+__global__ __launch_bounds__(256) void bn_finalize_partials_kernel(const float* __restrict__ partials, int rows,
+                                                                   float* running_mean, float* running_var, int64_t* nbt,
+                                                                   float* save_mean, float* save_invstd, int C, double count,
+                                                                   float momentum, float eps) {
+  __shared__ double sh[16][16][2];
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double s = 0.0, q = 0.0;
+  if (c < C) {
+    for (int r = rg; r < rows; r += 16) {
+      const float2 v = *reinterpret_cast<const float2*>(partials + ((long)r * C + c) * 2);
+      s += (double)v.x;
+      q += (double)v.y;
+    }
+  }
+  sh[rg][cl][0] = s; sh[rg][cl][1] = q;
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+  if (rg != 0 || c >= C) return;
+  s = 0.0; q = 0.0;
+  for (int j = 0; j < 16; ++j) { s += sh[j][cl][0]; q += sh[j][cl][1]; }
+  const double m = s / count;
+  double var = q / count - m * m;
+  if (var < 0) var = 0;
+  save_mean[c] = (float)m;
+  save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  const double unbiased = count > 1 ? var * count / (count - 1) : var;
+  running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+  running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+}
+
+// y = relu(gamma (x - mean) invstd + beta) from saved statistics; grid (B*C, chunks)
+__global__ __launch_bounds__(256) void bn_apply_saved_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, float* __restrict__ y, int C,
+                                                             int HW, int relu) {
+  const int plane = blockIdx.x, c = plane % C;
+  const float sc = gamma[c] * invstd[c], sf = beta[c] - mean[c] * sc;
+  const float* xp = x + (long)plane * HW;
+  float* yp = y + (long)plane * HW;
+  if ((HW & 3) == 0) {
+    const float4* x4 = reinterpret_cast<const float4*>(xp);
+    float4* y4 = reinterpret_cast<float4*>(yp);
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < HW / 4; i += gridDim.y * 256) {
+      float4 v = x4[i];
+      v.x = v.x * sc + sf; v.y = v.y * sc + sf; v.z = v.z * sc + sf; v.w = v.w * sc + sf;
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      y4[i] = v;
+    }
+  } else {
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < HW; i += gridDim.y * 256) {
+      float v = xp[i] * sc + sf;
+      yp[i] = relu ? fmaxf(v, 0.f) : v;
+    }
+  }
+}
+
 __global__ void bn_eval_save_kernel(const float* rmean, const float* rvar, float* save_mean, float* save_invstd, int C, float eps) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
@@ -523,6 +584,23 @@ int mpa_bn_relu_train_fwd(const float* x, const float* gamma, const float* beta,
                      (const float*)nullptr, (const float*)nullptr, y, C, HW, count, eps, relu);
   MPA_LAUNCH(bn_finalize_kernel, dim3((unsigned)mpa_cdiv(C, 64)), dim3(64), 0, s, (const double*)stats_ws,
                      running_mean, running_var, num_batches_tracked, save_mean, save_invstd, C, count, momentum, eps);
+  return mpa_launch_status();
+}
+
+int mpa_bn_relu_train_fwd_partials(const float* x, const float* partials, int rows, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, int64_t* num_batches_tracked, float* y,
+                                   float* save_mean, float* save_invstd, int B, int C, int HW, float momentum, float eps,
+                                   int relu, void* stream) {
+  if (!x || !partials || rows <= 0 || !gamma || !beta || !running_mean || !running_var || !y || !save_mean || !save_invstd)
+    return MPA_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  MPA_LAUNCH(bn_finalize_partials_kernel, dim3((unsigned)mpa_cdiv(C, 16)), dim3(256), 0, s, partials, rows, running_mean,
+             running_var, num_batches_tracked, save_mean, save_invstd, C, (double)B * HW, momentum, eps);
+  int rc = mpa_launch_status();
+  if (rc) return rc;
+  const int chunks = (int)std::max<long>(1, std::min<long>(mpa_cdiv(HW, 1024), 64));
+  MPA_LAUNCH(bn_apply_saved_kernel, dim3(B * C, chunks), dim3(256), 0, s, x, gamma, beta, (const float*)save_mean,
+             (const float*)save_invstd, y, C, HW, relu);
   return mpa_launch_status();
 }
 

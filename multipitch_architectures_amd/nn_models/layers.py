@@ -39,6 +39,10 @@ class Conv2d(nn.Module):
     def forward(self, x, act=ops.ACT_NONE, slope=0.0):
         return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, act, slope)
 
+    def forward_stats(self, x):
+        """(y, partial sums of y and y^2 per pixel tile and channel) for the BatchNorm2d that follows"""
+        return ops.conv2d_stats(x, self.weight, self.bias, self.stride, self.padding)
+
     def extra_repr(self):
         return f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, padding={self.padding}"
 
@@ -55,11 +59,11 @@ class BatchNorm2d(nn.Module):
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
-    def forward(self, x, relu=False):
+    def forward(self, x, relu=False, partials=None):
         if x.shape[1] != self.num_features:
             raise RuntimeError(f"BatchNorm2d: expected {self.num_features} channels, got {x.shape[1]}")
         return ops.batchnorm_relu(x, self.weight, self.bias, self.running_mean, self.running_var,
-                                  self.num_batches_tracked, self.training, self.momentum, relu)
+                                  self.num_batches_tracked, self.training, self.momentum, relu, partials)
 
 
 class LayerNorm(nn.Module):

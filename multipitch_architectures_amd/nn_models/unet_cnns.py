@@ -14,7 +14,8 @@ from .layers import (BatchNorm2d, Conv2d, ConvActPoolDrop, Dropout, LayerNorm, L
 
 
 class _DoubleConvSeq(nn.Sequential):
-    """Conv -> BN -> ReLU -> Dropout, twice; BN+ReLU run as one fused kernel."""
+    """Conv -> BN -> ReLU -> Dropout, twice.  In training the convolution's store epilogue produces the partial sums
+    the BatchNorm statistics are made of (no statistics pass over its output); BN-apply + ReLU run as one kernel."""
 
     def forward(self, x):
         mods = list(self)
@@ -22,7 +23,11 @@ class _DoubleConvSeq(nn.Sequential):
         i = 0
         while i < len(mods):
             conv, bn = mods[i], mods[i + 1]
-            h = bn(conv(h), relu=True)
+            if bn.training:
+                y, partials = conv.forward_stats(h)
+                h = bn(y, relu=True, partials=partials)
+            else:
+                h = bn(conv(h), relu=True)
             i += 3
             if i < len(mods) and isinstance(mods[i], Dropout):
                 h = mods[i](h)

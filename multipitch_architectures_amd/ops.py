@@ -146,8 +146,13 @@ def _probed(kind, desc, fn):
 
 # --------------------------------------------------------------------------- convolution
 class Conv2dFn(torch.autograd.Function):
+    """nn.Conv2d.  with_stats: the convolution sits in front of a BatchNorm2d (double_conv, unet_cnns.py:49-59) and its
+    store epilogue also leaves per-(pixel tile, channel) partial sums of y and y^2 -- returned as a second,
+    non-differentiable output that `batchnorm_relu(..., partials=...)` turns into the batch statistics without another
+    pass over y."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, act, slope):
+    def forward(ctx, x, weight, bias, stride, padding, act, slope, with_stats=False):
         x, weight, bias = _c(x, "conv input"), _c(weight, "conv weight"), _c(bias, "conv bias")
         B, Cin, H, W = x.shape
         Cout, Cin_w, kh, kw = weight.shape
@@ -158,14 +163,25 @@ class Conv2dFn(torch.autograd.Function):
             raise RuntimeError(f"conv2d: kernel {(kh, kw)} larger than padded input {(H, W)}")
         y = torch.empty((B, Cout, d.OH, d.OW), dtype=torch.float32, device=x.device)
         wp = _packed(weight, d, 0)
-        _chk(_probed("fwd", d, lambda: _lib().mpa_conv2d_fwd(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(y), act,
-                                                             float(slope), _s())), "mpa_conv2d_fwd")
         ctx.desc, ctx.act, ctx.slope, ctx.has_bias = d, act, float(slope), bias is not None
         ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
+        if with_stats:
+            if act != ACT_NONE:
+                raise RuntimeError("conv2d(with_stats=True) is the convolution in front of a BatchNorm: no activation")
+            rows = _lib().mpa_conv2d_fwd_stats_rows(ctypes.byref(d))
+            if rows < 0:
+                L.check(int(rows), "mpa_conv2d_fwd_stats_rows")
+            partials = torch.empty((int(rows), Cout, 2), dtype=torch.float32, device=x.device)
+            _chk(_probed("fwd", d, lambda: _lib().mpa_conv2d_fwd_stats(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(y),
+                                                                       _p(partials), _s())), "mpa_conv2d_fwd_stats")
+            ctx.mark_non_differentiable(partials)
+            return y, partials
+        _chk(_probed("fwd", d, lambda: _lib().mpa_conv2d_fwd(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(y), act,
+                                                             float(slope), _s())), "mpa_conv2d_fwd")
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dpartials=None):
         x, weight, y = ctx.saved_tensors
         d, lib = ctx.desc, _lib()
         dy = _c(dy, "conv grad")
@@ -189,7 +205,12 @@ class Conv2dFn(torch.autograd.Function):
             _chk(_probed("wgrad", d, lambda: lib.mpa_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(db),
                                                                        _p(ws), int(nbytes), _s())),
                  "mpa_conv2d_bwd_weight")
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
+
+
+def conv2d_stats(x, weight, bias, stride=(1, 1), padding=(0, 0)):
+    """(y, partials): convolution + the partial sums its BatchNorm needs (see Conv2dFn)"""
+    return Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(padding), ACT_NONE, 0.0, True)
 
 
 def conv2d(x, weight, bias, stride=(1, 1), padding=(0, 0), act=ACT_NONE, slope=0.0):
@@ -290,14 +311,23 @@ class BatchNormReLUFn(torch.autograd.Function):
     """nn.BatchNorm2d (+ fused nn.ReLU) of double_conv -- unet_cnns.py:51-52."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, nbt, training, momentum, relu):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, nbt, training, momentum, relu, partials=None):
         x, gamma, beta = _c(x), _c(gamma), _c(beta)
         B, C, H, W = x.shape
         y = torch.empty_like(x)
         save_mean = torch.empty(C, dtype=torch.float32, device=x.device)
         save_invstd = torch.empty_like(save_mean)
         lib = _lib()
-        if training:
+        if training and partials is not None:
+            # batch statistics from the producing convolution's epilogue: no statistics pass over x
+            if partials.shape[1:] != (C, 2):
+                raise RuntimeError(f"batchnorm: partial sums of shape {tuple(partials.shape)} for {C} channels")
+            _chk(lib.mpa_bn_relu_train_fwd_partials(_p(x), _p(partials), partials.shape[0], _p(gamma), _p(beta),
+                                                   _p(running_mean), _p(running_var),
+                                                   ctypes.c_void_p(nbt.data_ptr()) if nbt is not None else None, _p(y),
+                                                   _p(save_mean), _p(save_invstd), B, C, H * W, float(momentum), BN_EPS,
+                                                   int(relu), _s()), "mpa_bn_relu_train_fwd_partials")
+        elif training:
             ws = torch.empty(2 * C, dtype=torch.float64, device=x.device)
             _chk(lib.mpa_bn_relu_train_fwd(_p(x), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
                                           ctypes.c_void_p(nbt.data_ptr()) if nbt is not None else None, _p(y),
@@ -323,11 +353,11 @@ class BatchNormReLUFn(torch.autograd.Function):
         _chk(_lib().mpa_bn_relu_bwd(_p(dy), _p(x), None, _p(gamma), _p(beta), _p(save_mean), _p(save_invstd), _p(dx), _p(dgamma),
                                    _p(dbeta), ctypes.c_void_p(ws.data_ptr()), B, C, H * W, int(ctx.relu),
                                    int(ctx.training), _s()), "mpa_bn_relu_bwd")
-        return dx, dgamma, dbeta, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None
 
 
-def batchnorm_relu(x, gamma, beta, running_mean, running_var, nbt, training, momentum=0.1, relu=True):
-    return BatchNormReLUFn.apply(x, gamma, beta, running_mean, running_var, nbt, training, momentum, relu)
+def batchnorm_relu(x, gamma, beta, running_mean, running_var, nbt, training, momentum=0.1, relu=True, partials=None):
+    return BatchNormReLUFn.apply(x, gamma, beta, running_mean, running_var, nbt, training, momentum, relu, partials)
 
 
 # --------------------------------------------------------------------------- pooling / upsampling

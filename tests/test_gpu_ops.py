@@ -161,6 +161,44 @@ POOL_CASES = [((2, 2), (2, 2), (0, 0), (3, 5, 75, 216)), ((2, 2), (2, 2), (0, 0)
               ((13, 1), (1, 1), (3, 0), (1, 2, 20, 7)), ((13, 1), (1, 1), (6, 0), (3, 2, 174, 72))]
 
 
+STATS_CASES = [(2, 6, 75, 216, 16, 15, 15, 7, 7), (1, 16, 75, 216, 128, 15, 15, 7, 7), (3, 64, 9, 27, 128, 5, 5, 2, 2),
+               (5, 128, 4, 13, 128, 3, 3, 1, 1), (2, 70, 20, 40, 70, 15, 15, 7, 7), (3, 8, 37, 108, 6, 9, 9, 4, 4),
+               (2, 3, 11, 13, 5, 3, 3, 1, 1), (33, 16, 18, 54, 30, 9, 9, 4, 4)]
+
+
+@pytest.mark.parametrize("case", STATS_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_epilogue_partial_sums_are_the_batchnorm_statistics(dev, case):
+    """conv2d_stats: the partial sums the store epilogue leaves (wide 16-byte path and scalar path, every tile shape the
+    planner picks here) add up to sum(y), sum(y^2) per channel, and BatchNorm fed with them equals BatchNorm computing its
+    own statistics -- output, running statistics and all three gradients."""
+    from multipitch_architectures_amd import ops
+    B, Cin, H, W, Cout, kh, kw, ph, pw = case
+    x = _rand((B, Cin, H, W), 1).to(dev)
+    w = (_rand((Cout, Cin, kh, kw), 2) * (2.0 / (Cin * kh * kw)) ** 0.5).to(dev).requires_grad_(True)
+    b = (_rand((Cout,), 3) * 0.5).to(dev).requires_grad_(True)
+    y0 = ops.conv2d(x, w, b, (1, 1), (ph, pw))
+    y, partials = ops.conv2d_stats(x, w, b, (1, 1), (ph, pw))
+    assert torch.equal(y, y0) and not partials.requires_grad and partials.shape[1:] == (Cout, 2)
+    yd = y.detach().double()
+    tot = partials.double().sum(0)
+    _close(tot[:, 0], yd.sum((0, 2, 3)), 2e-5 * max(1.0, float(yd.abs().mean()) * B * H * W / max(float(yd.sum((0, 2, 3)).abs().max()), 1e-9)) , "sum")
+    _close(tot[:, 1], (yd * yd).sum((0, 2, 3)), 2e-6, "sum of squares")
+    gamma, beta = (_rand((Cout,), 4) * 0.3 + 1).to(dev), (_rand((Cout,), 5) * 0.2).to(dev)
+    outs = []
+    for use_partials in (False, True):
+        g_, b_ = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        rm, rv, nbt = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev), torch.zeros((), dtype=torch.long, device=dev)
+        w.grad = None
+        yy, pp = ops.conv2d_stats(x, w, b, (1, 1), (ph, pw))
+        z = ops.batchnorm_relu(yy, g_, b_, rm, rv, nbt, True, 0.1, True, pp if use_partials else None)
+        z.backward(_rand(tuple(z.shape), 6).to(dev))
+        outs.append((z.detach(), rm, rv, int(nbt), g_.grad, b_.grad, w.grad.clone()))
+    a, c = outs
+    assert a[3] == c[3] == 1
+    for i, what in ((0, "z"), (1, "running_mean"), (2, "running_var"), (4, "dgamma"), (5, "dbeta"), (6, "dw")):
+        _close(c[i], a[i], 2e-5, what)
+
+
 @pytest.mark.parametrize("k,s,p,shape", POOL_CASES)
 def test_maxpool(dev, k, s, p, shape):
     from multipitch_architectures_amd import ops
