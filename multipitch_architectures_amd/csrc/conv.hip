@@ -76,7 +76,7 @@ FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
     if ((NB == 3) != (phase && phaseX == 3)) continue;      // 48-cout tiles exactly for the 3-phase stores
     const int COT = NB * 16;
     const int coTiles = (int)mpa_cdiv(Cout, COT);
-    if (ni > 0 && (long)coTiles * COT >= (long)mpa_cdiv(Cout, 16) * 16 + 32 && NB > 1) continue;   // too much cout padding
+    if (ni > 0 && (long)coTiles * COT > (long)mpa_cdiv(Cout, 16) * 16 + 32 && NB > 1) continue;   // too much cout padding
     const int COTP = (COT % 32 == 0) ? COT + 16 : COT;   // filter-slab pitch == 16 (mod 32): conflict-free A reads
     for (int pi = 0; pi < 6; ++pi) {
       if ((pbs[pi] == 12 && NB > 2) || (pbs[pi] == 8 && NB > 4)) continue;   // accumulator budget
@@ -971,7 +971,12 @@ WgPlan plan_wgrad(const mpa_conv_desc* d) {
     pl.nPerBlock = 4 * pl.NTW * 16;
     pl.nTiles = (int)mpa_cdiv(Ntot, pl.nPerBlock);
     pl.XCH = std::min(d->Cin, (pl.nPerBlock + khkw - 2) / khkw + 1);
-    const double pad_eff = ((double)pl.coTiles * pl.COT / d->Cout) * ((double)pl.nTiles * pl.nPerBlock / Ntot);
+    // cost of a variant = cost of one (pixel tile, block) x the number of (cout tile, tap tile) blocks that have to visit
+    // every pixel tile.  (Round 1 multiplied by the padding ratio only, which compared the *per-block* cost of variants
+    // whose blocks cover different amounts of work: for 128->200 3x3 it picked 7 x 3 blocks of <2,8> over 3 x 3 of <5,6>.)
+    static const bool old_norm = getenv("MPA_WG_COSTNORM") && atoi(getenv("MPA_WG_COSTNORM")) == 0;   // diagnostics
+    const double pad_eff = old_norm ? ((double)pl.coTiles * pl.COT / d->Cout) * ((double)pl.nTiles * pl.nPerBlock / Ntot)
+                                    : (double)pl.coTiles * pl.nTiles / 8.0;
     static const int force_txn = getenv("MPA_WG_TXN") ? atoi(getenv("MPA_WG_TXN")) : 0;   // diagnostics
     // dY-from-global variant: exact tiling of 4-aligned rows, stride 1 (any variant) or the head's stride 3 (<5,6>)
     const char* ga_env = getenv("MPA_WG_GA");            // diagnostics / tests: "0" = never, "force" = whenever feasible
