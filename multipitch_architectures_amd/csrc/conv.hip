@@ -41,7 +41,7 @@ struct FwdPlan {
 // Measured: +4..8 % for NB <= 2; the 64-cout tile (NB = 4, already at 1 operand read per 2.7 MFMAs) loses 5 % to the
 // extra live registers, so it keeps the tap-major layout.
 inline int fwd_kw_special(int kw, int NB, int PB) {
-  return ((kw == 15 || kw == 9 || kw == 5 || kw == 3) && PB >= 4 && (NB <= 2 || NB * PB <= 24)) ? kw : 0;   // <4,8> would need > 256 VGPRs
+  return ((kw == 15 || kw == 9 || kw == 5 || kw == 3) && PB >= 4 && (NB <= 2 || NB * PB <= 30)) ? kw : 0;   // <4,8> would need > 256 VGPRs
 }
 
 inline int round_mod(int v, int m, int r) {  // smallest x >= v with x % m == r
@@ -788,7 +788,7 @@ int launch_fwd_one(const FwdPlan& pl, const ConvFwdParams& p, dim3 grid, hipStre
 
 template <int NB, int PB>
 int launch_fwd_kw(const FwdPlan& pl, const ConvFwdParams& p, dim3 grid, hipStream_t s) {
-  if constexpr (PB >= 4 && (NB <= 2 || NB * PB <= 24)) {
+  if constexpr (PB >= 4 && (NB <= 2 || NB * PB <= 30)) {
     if (pl.KWS == 15) return launch_fwd_one<NB, PB, 15>(pl, p, grid, s);
     if (pl.KWS == 9) return launch_fwd_one<NB, PB, 9>(pl, p, grid, s);
     if (pl.KWS == 5) return launch_fwd_one<NB, PB, 5>(pl, p, grid, s);
@@ -1425,6 +1425,7 @@ struct Wg15Params {
   int B, Cin, H, W, Cout, OH, OW;
   int COT, TH, TW, DP, tilesY, tilesX, IH, IW, DCP, S, Ntot, TX64, TD64;
   int quad;  // 16-byte LDS-DMA staging (aligned geometry): the X window then starts one column further left (ox0-8)
+  int co_base;   // first cout of this launch's cout tiles (remainder launch: couts past the last full NBC = 2 tile)
   int dbg;   // diagnostics (env MPA_DEBUG_WG15): 1 = stage only the first tile, 2 = skip the MFMA loop, 3 = 1 + no barriers
 };
 
@@ -1599,7 +1600,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad15g_kernel(const Wg15Params 
     const float* imgb = p.dy + (long)b * p.Cout * plane;
     const int img_elems = p.Cout * plane;
     auto dy_rsrc = [&](int cb, int py, int col, bool on) {
-      const int u = (cot * p.COT + cb * 16) * plane + (oy0 + py) * p.OW + ox0 + col;
+      const int u = (p.co_base + cot * p.COT + cb * 16) * plane + (oy0 + py) * p.OW + ox0 + col;
       const int left = (on && oy0 + py < p.OH && u < img_elems) ? (img_elems - u) * 4 : 0;
       return __builtin_amdgcn_make_buffer_rsrc((void*)(imgb + u), 0, left, 0x00020000);
     };
@@ -1722,7 +1723,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad15g_kernel(const Wg15Params 
       for (int cb = 0; cb < NBC; ++cb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int co = cot * p.COT + cb * 16 + kq * 4 + r;
+          const int co = p.co_base + cot * p.COT + cb * 16 + kq * 4 + r;
           if (co < p.Cout) out[(long)co * NtotP + ci * 225 + t * 15 + l16] = acc[cb][t][r];
         }
   }
@@ -1732,7 +1733,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad15g_kernel(const Wg15Params 
       float v = bs[cb];
       v += __shfl_xor(v, 16, 64);
       v += __shfl_xor(v, 32, 64);
-      const int co = cot * p.COT + cb * 16 + l16;
+      const int co = p.co_base + cot * p.COT + cb * 16 + l16;
       if (kq == 0 && co < p.Cout) out[(long)co * NtotP + p.Ntot] = v;
     }
   }
@@ -1741,6 +1742,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad15g_kernel(const Wg15Params 
 struct Wg15Plan {
   int NBC, CIW, COT, coTiles, ciGroups, TH, TW, DP, tilesY, tilesX, IH, IW, DCP, S, TX64, TD64, quad;
   int ga;    // conv_wgrad15g_kernel: dY operand from global memory, LDS holds the X tile only
+  int rem_split;   // the last, at most half-filled 32-cout tile runs as a second launch with 16-cout tiles
   size_t lds_bytes;
   bool ok;
 };
@@ -1808,7 +1810,12 @@ Wg15Plan plan_wgrad15(const mpa_conv_desc* d) {
   if (!pl.ok) return pl;
   const long totalTiles = (long)d->B * pl.tilesY * pl.tilesX;
   const long per_cu = std::max<long>(1, std::min<long>(2, (160 * 1024) / (long)pl.lds_bytes));
-  const long slots = 256 * per_cu, groups = (long)pl.ciGroups * pl.coTiles;
+  // Couts that fill the last 32-cout tile by at most half (70 = 2 x 32 + 6: DRCNN:L's prefilters) go to a second
+  // launch with 16-cout tiles: 80 instead of 96 cout rows of MFMA work (-17 % on those layers).  Both launches share
+  // S (the workspace slices), chosen so that the main launch is a whole number of rounds.
+  const int rem = d->Cout % 32;
+  pl.rem_split = (pl.ga && pl.NBC == 2 && rem > 0 && rem <= 16 && pl.coTiles > 1) ? 1 : 0;
+  const long slots = 256 * per_cu, groups = (long)pl.ciGroups * (pl.coTiles - pl.rem_split);
   long S = std::max<long>(1, (2 * slots) / groups);
   if (S > totalTiles) S = totalTiles;
   if (S > 1024) S = 1024;
@@ -2039,13 +2046,22 @@ int mpa_conv2d_bwd_weight(const mpa_conv_desc* d, const float* x, const float* d
       }
       const bool tl = (p15.DP & 15) != 0;
       const bool ev = ((p15.DP >> 4) & 1) == 0;
+      // (remainder launch: see plan_wgrad15)
+      const bool split_rem = p15.rem_split != 0;
 #define MPA_WG15G_GO(...) MPA_LAUNCH((conv_wgrad15g_kernel<__VA_ARGS__>), grid15, dim3(256), p15.lds_bytes, s15, q)
-      if (p15.NBC == 1) {
-        if (tl) { if (ev) MPA_WG15G_GO(1, true, true); else MPA_WG15G_GO(1, true, false); }
-        else { if (ev) MPA_WG15G_GO(1, false, true); else MPA_WG15G_GO(1, false, false); }
-      } else {
-        if (tl) { if (ev) MPA_WG15G_GO(2, true, true); else MPA_WG15G_GO(2, true, false); }
-        else { if (ev) MPA_WG15G_GO(2, false, true); else MPA_WG15G_GO(2, false, false); }
+      for (int part = 0; part < (split_rem ? 2 : 1); ++part) {
+        int nbc = p15.NBC;
+        if (split_rem) {
+          if (part == 0) { grid15.z = (unsigned)(p15.coTiles - 1); q.co_base = 0; q.COT = 32; }
+          else { grid15.z = 1; q.co_base = (p15.coTiles - 1) * 32; q.COT = 16; nbc = 1; }
+        }
+        if (nbc == 1) {
+          if (tl) { if (ev) MPA_WG15G_GO(1, true, true); else MPA_WG15G_GO(1, true, false); }
+          else { if (ev) MPA_WG15G_GO(1, false, true); else MPA_WG15G_GO(1, false, false); }
+        } else {
+          if (tl) { if (ev) MPA_WG15G_GO(2, true, true); else MPA_WG15G_GO(2, true, false); }
+          else { if (ev) MPA_WG15G_GO(2, false, true); else MPA_WG15G_GO(2, false, false); }
+        }
       }
 #undef MPA_WG15G_GO
     } else

@@ -8,10 +8,13 @@ from multipitch_architectures_amd.losses import BCELoss
 from multipitch_architectures_amd.optim import AdamW
 from multipitch_architectures_amd.synth import synth_batch
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-cfg = CONFIGS["SAUnet:L"]; dev = torch.device("cuda:0")
+cfg = CONFIGS[sys.argv[2] if len(sys.argv) > 2 else "SAUnet:L"]; dev = torch.device("cuda:0")
 torch.manual_seed(0)
 model = getattr(nn_models, cfg["cls"])(**cfg["kwargs"]).to(dev).train()
-opt = AdamW(model.parameters(), lr=1e-3, weight_decay=0.01); loss_fn = BCELoss()
+opt = AdamW(model.parameters(), lr=1e-3, weight_decay=0.01); _bce = BCELoss()
+from multipitch_architectures_amd.losses import PolyphonyLoss
+_pl = PolyphonyLoss()
+loss_fn = lambda res, y: _pl(res[0], res[1], y) if isinstance(res, tuple) else _bce(res, y)
 x, y = synth_batch(B, 75); x, y = x.to(dev), y.to(dev)
 def step():
     loss = loss_fn(model(x), y); opt.zero_grad(); loss.backward(); opt.step()
