@@ -150,6 +150,13 @@ int mpa_add_rows_bcast(const float* x, const float* pe, float* y, int B, int64_t
  * C[M,N] (+)= A[M,K] * op(B) (+ bias[N]) with act; A(m,k)=A[m*lda_m+k*lda_k], B(k,n)=Bm[k*ldb_k+n*ldb_n]. */
 int mpa_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float* Bm, int64_t ldb_k, int64_t ldb_n,
              const float* bias, float* C, int64_t ldc, int M, int N, int K, int accumulate, int act, void* stream);
+/* nbatch <= 4 products of identical shape and strides in one launch (the q/k/v projections of transformer_enc_layer and
+ * the three in-projections of nn.MultiheadAttention, unet_cnns.py:131-135,153): problem b uses A[b], B[b], bias[b], C[b]
+ * (host arrays of device pointers, read at launch).  shared_c != 0: every C[b] is the same matrix and receives the SUM of
+ * the products (input gradient of three projections of one tensor); it is zeroed first and added to atomically.   */
+int mpa_gemm_batched(int nbatch, const float* const* A, int64_t lda_m, int64_t lda_k, const float* const* B, int64_t ldb_k,
+                     int64_t ldb_n, const float* const* bias /*nullable*/, float* const* C, int64_t ldc, int M, int N, int K,
+                     int shared_c, int act, void* stream);
 /* column sums of a (rows, N) matrix (Linear bias gradients) */
 int mpa_colsum(const float* x, float* out, int64_t rows, int N, int accumulate, void* stream);
 

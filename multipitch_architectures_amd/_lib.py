@@ -81,6 +81,7 @@ SIGNATURES = {
     "mpa_channel_sum": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "mpa_add_rows_bcast": (c_int, [_P, _P, _P, c_int, c_int64, _P]),
     "mpa_gemm": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P]),
+    "mpa_gemm_batched": (c_int, [c_int, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P]),
     "mpa_colsum": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
     "mpa_attn_batchaxis_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "mpa_attn_batchaxis_bwd": (c_int, [_P] * 9 + [c_int, c_int, c_int, c_int, _P]),

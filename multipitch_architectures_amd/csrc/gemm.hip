@@ -19,6 +19,13 @@ struct GemmParams {
   long lda_m, lda_k, ldb_k, ldb_n, ldc;
   int M, N, K, accumulate, act;
   int kchunk;   // split-K: blockIdx.z owns k in [z*kchunk, (z+1)*kchunk); partial results are atomically added into C
+  // batched launch (mpa_gemm_batched): nbatch problems of identical shape and strides, blockIdx.z = batch * zsplits + split.
+  // atomic != 0: the problems share C (sum over the batch), so every workgroup adds atomically into the zeroed C.
+  int nbatch, zsplits, atomic;
+  const float* Ab[4];
+  const float* Bb[4];
+  const float* biasb[4];
+  float* Cb[4];
 };
 
 // Operand tile staging, split in two halves so that the global loads of k-tile t+1 are in flight while the MFMAs of
@@ -129,7 +136,14 @@ __device__ __forceinline__ void tile_load_fast(TileRegs<R>& t, TileIter<R>& it_)
 
 // block = 2x2 waves, wave tile = (WM*16) x (WN*16)
 template <int WM, int WN>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pp) {
+  GemmParams p = pp;
+  int zsplit = blockIdx.z;
+  if (pp.nbatch > 1) {
+    const int bi = blockIdx.z / pp.zsplits;
+    zsplit = blockIdx.z - bi * pp.zsplits;
+    p.A = pp.Ab[bi]; p.B = pp.Bb[bi]; p.bias = pp.biasb[bi]; p.C = pp.Cb[bi];
+  }
   constexpr int BMt = 2 * WM * 16, BNt = 2 * WN * 16;
   constexpr int AF = (BMt * (BK + 4) > BK * (BMt + 16)) ? BMt * (BK + 4) : BK * (BMt + 16);
   constexpr int BF = (BNt * (BK + 4) > BK * (BNt + 16)) ? BNt * (BK + 4) : BK * (BNt + 16);
@@ -154,8 +168,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 
   TileRegs<BMt> ra;
   TileRegs<BNt> rb;
-  const bool splitk = gridDim.z > 1;
-  const int kbeg = blockIdx.z * p.kchunk;
+  const bool splitk = (pp.nbatch > 1 ? pp.zsplits > 1 : gridDim.z > 1) || pp.atomic != 0;
+  const int kbeg = zsplit * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
   // fast path: 16-byte loads, unit stride along one of the two dims, and (for r-contiguous operands) whole 4-row groups
   const bool a_fast = a_vec && (p.lda_k == 1 || (p.lda_m == 1 && m0 + BMt <= p.M));
@@ -250,7 +264,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     for (int j = 0; j < WN; ++j) {
       const int n = n0 + wn + j * 16 + l16;
       if (n >= p.N) continue;
-      const float bv = (p.bias && blockIdx.z == 0) ? p.bias[n] : 0.f;
+      const float bv = (p.bias && zsplit == 0) ? p.bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm + i * 16 + kq * 4 + r;
@@ -266,18 +280,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 
 template <int WM, int WN>
 void launch_gemm(const GemmParams& p, int splits, hipStream_t s) {
-  dim3 grid((unsigned)mpa_cdiv(p.N, 2 * WN * 16), (unsigned)mpa_cdiv(p.M, 2 * WM * 16), (unsigned)splits);
+  dim3 grid((unsigned)mpa_cdiv(p.N, 2 * WN * 16), (unsigned)mpa_cdiv(p.M, 2 * WM * 16),
+            (unsigned)(splits * (p.nbatch > 1 ? p.nbatch : 1)));
   MPA_LAUNCH((gemm_kernel<WM, WN>), grid, dim3(256), 0, s, p);
 }
 
-}  // namespace
-
-extern "C" int mpa_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float* Bm, int64_t ldb_k, int64_t ldb_n,
-                        const float* bias, float* C, int64_t ldc, int M, int N, int K, int accumulate, int act,
-                        void* stream) {
-  if (!A || !Bm || !C || M <= 0 || N <= 0 || K <= 0) return MPA_ERR_ARG;
-  GemmParams p{A, Bm, bias, C, (long)lda_m, (long)lda_k, (long)ldb_k, (long)ldb_n, (long)ldc, M, N, K, accumulate, act, K};
-  hipStream_t s = (hipStream_t)stream;
+int gemm_impl(GemmParams p, int nbatch, int shared_c, hipStream_t s) {
+  const int M = p.M, N = p.N, K = p.K, act = p.act, accumulate = p.accumulate;
+  const long ldc = p.ldc;
+  float* C = p.C;
   // Pick tile and K-split by a small cost model: whole "rounds" of workgroups over 256 CUs x 2 resident workgroups,
   // each costing (its K extent + a fixed prologue/epilogue) x tile area / tile efficiency (the 64-wide tiles issue one
   // LDS operand read per MFMA, the 128x128 tile one per two).  Splitting K (atomic accumulation, no activation, order
@@ -292,7 +303,7 @@ extern "C" int mpa_gemm(const float* A, int64_t lda_m, int64_t lda_k, const floa
     // padding waste of partial tiles is paid in full
     for (int sp = 1; sp <= 32; sp *= 2) {
       if (sp > 1 && (act != MPA_ACT_NONE || K / sp < 256)) break;
-      const double rounds = (double)mpa_cdiv(blocks * sp, 512);
+      const double rounds = (double)mpa_cdiv(blocks * sp * nbatch, 512);
       const double cost = rounds * ((double)mpa_cdiv(K, sp) + 96.0) * TM[v] * TN[v] / EFF[v] * (sp > 1 ? 1.03 : 1.0);
       if (cost < best) { best = cost; variant = v; splits = sp; }
     }
@@ -300,9 +311,12 @@ extern "C" int mpa_gemm(const float* A, int64_t lda_m, int64_t lda_k, const floa
   if (splits > 1) {
     p.kchunk = (int)(mpa_cdiv(mpa_cdiv(K, splits), BK) * BK);
     splits = (int)mpa_cdiv(K, p.kchunk);
-    if (!accumulate) {
-      if (mpa_zero2d_async(C, sizeof(float) * ldc, sizeof(float) * N, M, s) != MPA_OK) return MPA_ERR_LAUNCH;
-    }
+  }
+  p.nbatch = nbatch; p.zsplits = splits; p.atomic = shared_c ? 1 : 0;
+  if ((splits > 1 || shared_c) && !accumulate) {
+    for (int b = 0; b < (shared_c ? 1 : nbatch); ++b)
+      if (mpa_zero2d_async(nbatch > 1 ? p.Cb[b] : C, sizeof(float) * ldc, sizeof(float) * N, M, s) != MPA_OK)
+        return MPA_ERR_LAUNCH;
   }
   switch (variant) {
     case 0: launch_gemm<4, 4>(p, splits, s); break;
@@ -311,4 +325,28 @@ extern "C" int mpa_gemm(const float* A, int64_t lda_m, int64_t lda_k, const floa
     default: launch_gemm<2, 2>(p, splits, s); break;
   }
   return mpa_launch_status();
+}
+
+}  // namespace
+
+extern "C" int mpa_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float* Bm, int64_t ldb_k, int64_t ldb_n,
+                        const float* bias, float* C, int64_t ldc, int M, int N, int K, int accumulate, int act,
+                        void* stream) {
+  if (!A || !Bm || !C || M <= 0 || N <= 0 || K <= 0) return MPA_ERR_ARG;
+  GemmParams p{A, Bm, bias, C, (long)lda_m, (long)lda_k, (long)ldb_k, (long)ldb_n, (long)ldc, M, N, K, accumulate, act, K};
+  return gemm_impl(p, 1, 0, (hipStream_t)stream);
+}
+
+extern "C" int mpa_gemm_batched(int nbatch, const float* const* A, int64_t lda_m, int64_t lda_k, const float* const* Bm,
+                                int64_t ldb_k, int64_t ldb_n, const float* const* bias, float* const* C, int64_t ldc, int M,
+                                int N, int K, int shared_c, int act, void* stream) {
+  if (nbatch < 1 || nbatch > 4 || !A || !Bm || !C || M <= 0 || N <= 0 || K <= 0) return MPA_ERR_ARG;
+  if (shared_c && act != MPA_ACT_NONE) return MPA_ERR_ARG;
+  GemmParams p{A[0], Bm[0], bias ? bias[0] : nullptr, C[0], (long)lda_m, (long)lda_k, (long)ldb_k, (long)ldb_n, (long)ldc,
+               M, N, K, 0, act, K};
+  for (int b = 0; b < nbatch; ++b) {
+    if (!A[b] || !Bm[b] || !C[b] || (shared_c && C[b] != C[0])) return MPA_ERR_ARG;
+    p.Ab[b] = A[b]; p.Bb[b] = Bm[b]; p.biasb[b] = bias ? bias[b] : nullptr; p.Cb[b] = C[b];
+  }
+  return gemm_impl(p, nbatch, shared_c, (hipStream_t)stream);
 }

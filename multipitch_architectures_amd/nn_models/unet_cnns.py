@@ -145,7 +145,8 @@ class transformer_enc_layer(nn.Module):
             t = self.dropout_pe(ops.transpose_last2(xf, self._pe_on(x.device)))
         else:
             t = ops.transpose_last2(xf)                          # (B,S,E)
-        x1 = self.attn(self.q_linear(t), self.k_linear(t), self.v_linear(t))[0]
+        q, k, v = ops.qkv_linear(t, self.q_linear.weight, self.k_linear.weight, self.v_linear.weight)
+        x1 = self.attn(q, k, v)[0]
         x1_proj = self.o_linear(x1)
         x1_norm = self.layernorm1(t, self.dropout1(x1_proj))
         x2 = self.mlp[2](self.mlp[0](x1_norm, ops.ACT_RELU))

@@ -537,12 +537,40 @@ def transpose_last2(x, pe=None):
 
 
 # --------------------------------------------------------------------------- linear / attention
+class _GemmKey:
+    """what the kernel probe sees of a GEMM launch (the conv launches pass their mpa_conv_desc)"""
+
+    def __init__(self, *k):
+        self._k = k
+
+    def key(self):
+        return self._k
+
+
 def _gemm(A, lda_m, lda_k, Bm, ldb_k, ldb_n, bias, C, ldc, M, N, K, accumulate=0, act=ACT_NONE):
-    _chk(_lib().mpa_gemm(A, lda_m, lda_k, Bm, ldb_k, ldb_n, bias, C, ldc, M, N, K, accumulate, act, _s()), "mpa_gemm")
+    call = lambda: _lib().mpa_gemm(A, lda_m, lda_k, Bm, ldb_k, ldb_n, bias, C, ldc, M, N, K, accumulate, act, _s())
+    if _Probe.match is not None:
+        _chk(_probed("gemm", _GemmKey(M, N, K, int(lda_k == 1), int(ldb_k == 1), accumulate, act), call), "mpa_gemm")
+    else:
+        _chk(call(), "mpa_gemm")
 
 
 def _ptr_off(t, off_floats=0):
     return ctypes.c_void_p(t.data_ptr() + 4 * off_floats)
+
+
+def _gemm_batched(As, lda_m, lda_k, Bs, ldb_k, ldb_n, biases, Cs, ldc, M, N, K, shared_c=0, act=ACT_NONE):
+    """up to 4 products of one shape in one launch; As/Bs/biases/Cs: lists of raw device addresses (ints)"""
+    n = len(As)
+    arr = lambda vals: (ctypes.c_void_p * n)(*vals)
+    a, b, c = arr(As), arr(Bs), arr(Cs)
+    bi = arr(biases) if biases is not None else None
+    call = lambda: _lib().mpa_gemm_batched(n, a, lda_m, lda_k, b, ldb_k, ldb_n, bi, c, ldc, M, N, K, shared_c, act, _s())
+    if _Probe.match is not None:
+        _chk(_probed("gemm", _GemmKey(M, N, K, int(lda_k == 1), int(ldb_k == 1), -n if shared_c else n, act), call),
+             "mpa_gemm_batched")
+    else:
+        _chk(call(), "mpa_gemm_batched")
 
 
 class LinearFn(torch.autograd.Function):
@@ -589,19 +617,55 @@ def linear(x, weight, bias=None, act=ACT_NONE):
     return LinearFn.apply(x, weight, bias, act)
 
 
+class QKVLinearFn(torch.autograd.Function):
+    """q_linear / k_linear / v_linear of transformer_enc_layer (bias-free, unet_cnns.py:131-133,153) applied to the same
+    tensor: three products in one launch, and in backward one launch each for the three weight gradients and for the
+    input gradient (the sum of the three products)."""
+
+    @staticmethod
+    def forward(ctx, t, wq, wk, wv):
+        t, wq, wk, wv = _c(t), _c(wq), _c(wk), _c(wv)
+        N, K = wq.shape
+        if t.shape[-1] != K or wk.shape != wq.shape or wv.shape != wq.shape:
+            raise RuntimeError(f"qkv linear: input features {t.shape[-1]}, weights {tuple(wq.shape)}")
+        rows = t.numel() // K
+        outs = [torch.empty(t.shape[:-1] + (N,), dtype=torch.float32, device=t.device) for _ in range(3)]
+        _gemm_batched([t.data_ptr()] * 3, K, 1, [w.data_ptr() for w in (wq, wk, wv)], 1, K, None,
+                      [o.data_ptr() for o in outs], N, rows, N, K)
+        ctx.save_for_backward(t, wq, wk, wv)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        t, wq, wk, wv = ctx.saved_tensors
+        gs = [_c(g) for g in (dq, dk, dv)]
+        N, K = wq.shape
+        rows = t.numel() // K
+        dt = torch.empty_like(t)
+        _gemm_batched([g.data_ptr() for g in gs], N, 1, [w.data_ptr() for w in (wq, wk, wv)], K, 1, None,
+                      [dt.data_ptr()] * 3, K, rows, K, N, shared_c=1)
+        dws = [torch.empty_like(wq) for _ in range(3)]
+        _gemm_batched([g.data_ptr() for g in gs], 1, N, [t.data_ptr()] * 3, K, 1, None, [d.data_ptr() for d in dws], K,
+                      N, K, rows)
+        return dt, dws[0], dws[1], dws[2]
+
+
+def qkv_linear(t, wq, wk, wv):
+    return QKVLinearFn.apply(t, wq, wk, wv)
+
+
 class InProjFn(torch.autograd.Function):
-    """nn.MultiheadAttention's packed in-projection: q' = q Wq^T + bq etc. with W = in_proj_weight (3E,E)."""
+    """nn.MultiheadAttention's packed in-projection: q' = q Wq^T + bq etc. with W = in_proj_weight (3E,E); the three
+    products (and each kind of gradient) run as one batched launch."""
 
     @staticmethod
     def forward(ctx, q, k, v, w, b):
         q, k, v, w, b = _c(q), _c(k), _c(v), _c(w), _c(b)
         E = q.shape[-1]
         rows = q.numel() // E
-        outs = []
-        for i, t in enumerate((q, k, v)):
-            y = torch.empty_like(t)
-            _gemm(_p(t), E, 1, _ptr_off(w, i * E * E), 1, E, _ptr_off(b, i * E), _p(y), E, rows, E, E)
-            outs.append(y)
+        outs = [torch.empty_like(t) for t in (q, k, v)]
+        _gemm_batched([t.data_ptr() for t in (q, k, v)], E, 1, [w.data_ptr() + 4 * i * E * E for i in range(3)], 1, E,
+                      [b.data_ptr() + 4 * i * E for i in range(3)], [o.data_ptr() for o in outs], E, rows, E, E)
         ctx.save_for_backward(q, k, v, w)
         return tuple(outs)
 
@@ -611,16 +675,16 @@ class InProjFn(torch.autograd.Function):
         E = q.shape[-1]
         rows = q.numel() // E
         lib = _lib()
+        gs = [_c(g) for g in (dq, dk, dv)]
         dw = torch.empty_like(w)
         db = torch.empty(3 * E, dtype=torch.float32, device=q.device)
-        dins = []
-        for i, (t, g) in enumerate(((q, dq), (k, dk), (v, dv))):
-            g = _c(g)
-            dx = torch.empty_like(t)
-            _gemm(_p(g), E, 1, _ptr_off(w, i * E * E), E, 1, None, _p(dx), E, rows, E, E)
-            _gemm(_p(g), 1, E, _p(t), E, 1, None, _ptr_off(dw, i * E * E), E, E, E, rows)
+        dins = [torch.empty_like(t) for t in (q, k, v)]
+        wptr = [w.data_ptr() + 4 * i * E * E for i in range(3)]
+        _gemm_batched([g.data_ptr() for g in gs], E, 1, wptr, E, 1, None, [d.data_ptr() for d in dins], E, rows, E, E)
+        _gemm_batched([g.data_ptr() for g in gs], 1, E, [t.data_ptr() for t in (q, k, v)], E, 1, None,
+                      [dw.data_ptr() + 4 * i * E * E for i in range(3)], E, E, E, rows)
+        for i, g in enumerate(gs):
             _chk(lib.mpa_colsum(_p(g), _ptr_off(db, i * E), rows, E, 0, _s()), "mpa_colsum")
-            dins.append(dx)
         return dins[0], dins[1], dins[2], dw, db
 
 
