@@ -132,6 +132,10 @@ int mpa_dropout(const float* x, float* y, int64_t n, float p, const uint64_t* rn
 /* table[i] = host_ptrs[i], i < n: device pointer table written by kernels whose arguments carry the pointers (no
  * memcpy, nothing for the host to keep alive; capturable in a HIP graph)                                       */
 int mpa_store_ptrs(const void** table, const void* const* host_ptrs, int n, void* stream);
+/* dst[dst_offsets[i] .. + sizes[i]) = srcs[i][0 .. sizes[i]) for i < n: many tensors into one flat buffer with one
+ * launch per 32 tensors (the gradient buckets of the data-parallel averager; host arrays, read at launch)          */
+int mpa_gather_copy(float* dst, const float* const* srcs, const int64_t* dst_offsets, const int64_t* sizes, int n,
+                    void* stream);
 /* counter[0] += delta on the device (end-of-step advance of the dropout stream; capturable in a HIP graph)      */
 int mpa_u64_add(uint64_t* counter, uint64_t delta, void* stream);
 int mpa_add(const float* a, const float* b, float* y, int64_t n, void* stream);

@@ -72,6 +72,7 @@ SIGNATURES = {
     "mpa_act_bwd": (c_int, [_P, _P, _P, c_int64, c_int, c_float, _P]),
     "mpa_dropout": (c_int, [_P, _P, c_int64, c_float, _P, c_uint64, _P]),
     "mpa_u64_add": (c_int, [_P, c_uint64, _P]),
+    "mpa_gather_copy": (c_int, [_P, _P, _P, _P, c_int, _P]),
     "mpa_store_ptrs": (c_int, [_P, _P, c_int, _P]),
     "mpa_add": (c_int, [_P, _P, _P, c_int64, _P]),
     "mpa_axpy": (c_int, [c_float, _P, _P, c_int64, _P]),

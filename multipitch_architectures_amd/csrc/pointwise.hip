@@ -278,6 +278,20 @@ __global__ void store_ptrs_kernel(const void** __restrict__ table, PtrChunk c, i
   if ((int)threadIdx.x < n) table[threadIdx.x] = c.p[threadIdx.x];
 }
 
+// multi-tensor copy: up to 32 tensors into one flat buffer per launch (gradient buckets of the data-parallel averager)
+struct GatherArgs {
+  const float* src[32];
+  long off[32];
+  long n[32];
+};
+__global__ __launch_bounds__(256) void gather_copy_kernel(float* __restrict__ dst, GatherArgs a) {
+  const int t = blockIdx.y;
+  const float* __restrict__ s = a.src[t];
+  float* __restrict__ d = dst + a.off[t];
+  const long n = a.n[t];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) d[i] = s[i];
+}
+
 __global__ void u64_add_kernel(uint64_t* __restrict__ p, uint64_t delta) {
   if (threadIdx.x == 0 && blockIdx.x == 0) p[0] += delta;
 }
@@ -362,6 +376,25 @@ int mpa_store_ptrs(const void** table, const void* const* host_ptrs, int n, void
     const int m = n - o < 64 ? n - o : 64;
     for (int i = 0; i < m; ++i) c.p[i] = host_ptrs[o + i];
     MPA_LAUNCH(store_ptrs_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, table + o, c, m);
+    const int rc = mpa_launch_status();
+    if (rc) return rc;
+  }
+  return MPA_OK;
+}
+int mpa_gather_copy(float* dst, const float* const* srcs, const int64_t* dst_offsets, const int64_t* sizes, int n,
+                    void* stream) {
+  if (!dst || !srcs || !dst_offsets || !sizes || n < 0) return MPA_ERR_ARG;
+  for (int o = 0; o < n; o += 32) {
+    GatherArgs a{};
+    const int m = n - o < 32 ? n - o : 32;
+    long mx = 1;
+    for (int i = 0; i < m; ++i) {
+      if (!srcs[o + i] || sizes[o + i] < 0) return MPA_ERR_ARG;
+      a.src[i] = srcs[o + i]; a.off[i] = dst_offsets[o + i]; a.n[i] = sizes[o + i];
+      mx = std::max<long>(mx, sizes[o + i]);
+    }
+    dim3 grid((unsigned)std::max<long>(1, std::min<long>(mpa_cdiv(mx, 1024), 256)), (unsigned)m);
+    MPA_LAUNCH(gather_copy_kernel, grid, dim3(256), 0, (hipStream_t)stream, dst, a);
     const int rc = mpa_launch_status();
     if (rc) return rc;
   }

@@ -61,18 +61,45 @@ class GradientAverager:
         for p in plist:
             views.append(flat[off:off + p.numel()].view_as(p))
             off += p.numel()
-        b = {"params": plist, "flat": flat, "views": views, "pending": len(plist), "handle": None}
+        offs, off = [], 0
+        for p in plist:
+            offs.append(off)
+            off += p.numel()
+        b = {"params": plist, "flat": flat, "views": views, "pending": len(plist), "handle": None, "offsets": offs}
         for p in plist:
             self._owner[p] = b
         self.buckets.append(b)
 
     def _on_grad(self, p):
         b = self._owner[p]
-        i = next(j for j, q in enumerate(b["params"]) if q is p)
-        b["views"][i].copy_(p.grad)                    # device-to-device copy into the bucket (plumbing)
         b["pending"] -= 1
-        if b["pending"] == 0 and self.world > 1:
-            b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if b["pending"] == 0:
+            # the bucket is complete: gather its gradients into the flat buffer (one launch per 32 tensors instead of one
+            # copy per parameter -- 168 of them for SAUnet:L) and put it on the wire
+            self._gather(b)
+            if self.world > 1:
+                b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    @staticmethod
+    def _gather(b):
+        plist = [(i, p) for i, p in enumerate(b["params"]) if p.grad is not None]
+        if not plist:
+            return
+        if not b["flat"].is_cuda:           # gloo / CPU rehearsal of the communication logic only
+            for i, p in plist:
+                b["views"][i].copy_(p.grad)
+            return
+        import ctypes
+        n = len(plist)
+        for _, p in plist:
+            if not p.grad.is_contiguous() or p.grad.dtype != torch.float32:
+                raise RuntimeError("GradientAverager needs contiguous fp32 gradients")
+        srcs = (ctypes.c_void_p * n)(*[p.grad.data_ptr() for _, p in plist])
+        offs = (ctypes.c_int64 * n)(*[b["offsets"][i] for i, _ in plist])
+        sizes = (ctypes.c_int64 * n)(*[p.numel() for _, p in plist])
+        rc = L.load().mpa_gather_copy(ctypes.c_void_p(b["flat"].data_ptr()), srcs, offs, sizes, n,
+                                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        L.check(rc, "mpa_gather_copy")
 
     def finish(self):
         for b in self.buckets:
@@ -81,6 +108,7 @@ class GradientAverager:
                 for i, p in enumerate(b["params"]):
                     if p.grad is None:
                         b["views"][i].zero_()
+                self._gather(b)
                 if self.world > 1:
                     b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         for b in self.buckets:
