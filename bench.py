@@ -28,6 +28,8 @@ def parse_args(argv=None):
                     help="default: the batch BASELINE.json quotes for the configuration (256 for SAUnet:L)")
     ap.add_argument("--frames", type=int, default=75)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the patch-extraction / evaluation / segment-inference "
+                    "probes after the timed region (profiling runs)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying "
                     "the captured HIP graph of the step")
     return ap.parse_args(argv)
@@ -393,7 +395,7 @@ def main():
             out["step_mfma_frac"] = step_tflops / (PEAK_FP32_MFMA_TFLOPS * world)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, args.frames)
-        if world == 1:
+        if world == 1 and not args.no_extras:
             out["patch_extraction"] = patch_extraction_probe(B_loc, not args.no_cpu_baseline)
             out["eval_measures"] = eval_measures_probe(not args.no_cpu_baseline)
             out["segment_inference"] = segment_inference_probe(model)

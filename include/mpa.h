@@ -93,11 +93,12 @@ int mpa_bn_relu_train_fwd(const float* x, const float* gamma, const float* beta,
                           float* running_var, int64_t* num_batches_tracked /*nullable, += 1*/, float* y, float* save_mean,
                           float* save_invstd, double* stats_ws, int B, int C, int HW, float momentum, float eps, int relu,
                           void* stream);
-/* as mpa_bn_relu_train_fwd with the batch statistics taken from the producing convolution's partial sums */
+/* as mpa_bn_relu_train_fwd with the batch statistics taken from the producing convolution's partial sums;
+ * stage_ws (nullable: single-stage reduction): 64 * C * 2 doubles of scratch for the two-stage reduction of many rows */
 int mpa_bn_relu_train_fwd_partials(const float* x, const float* partials, int rows, const float* gamma, const float* beta,
                                    float* running_mean, float* running_var, int64_t* num_batches_tracked, float* y,
-                                   float* save_mean, float* save_invstd, int B, int C, int HW, float momentum, float eps,
-                                   int relu, void* stream);
+                                   float* save_mean, float* save_invstd, double* stage_ws, int B, int C, int HW,
+                                   float momentum, float eps, int relu, void* stream);
 int mpa_bn_relu_eval_fwd(const float* x, const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float* y, float* save_mean /*nullable*/, float* save_invstd /*nullable*/,
                          int B, int C, int HW, float eps, int relu, void* stream);

@@ -61,7 +61,7 @@ SIGNATURES = {
     "mpa_layernorm_rows_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_float, _P]),
     "mpa_layernorm_rows_bwd_ws": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, _P]),
     "mpa_bn_relu_train_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_int, _P]),
-    "mpa_bn_relu_train_fwd_partials": (c_int, [_P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_int, _P]),
+    "mpa_bn_relu_train_fwd_partials": (c_int, [_P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_int, _P]),
     "mpa_bn_relu_eval_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P]),
     "mpa_bn_relu_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "mpa_maxpool2d_fwd": (c_int, [_P, _P, _P] + [c_int] * 10 + [_P]),

@@ -315,9 +315,36 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, float* runn
 
 // Batch statistics from the per-(pixel tile, channel) partial sums the producing convolution left behind
 // (conv_fwd_kernel's epilogue): partials [rows][C][2] (sum, sum of squares; float) -> the same outputs as
-// bn_finalize_kernel.  One workgroup per 16 channels; 16 row groups accumulate in double and are combined through LDS in
-// a fixed order (run-to-run reproducible).
-__global__ __launch_bounds__(256) void bn_finalize_partials_kernel(const float* __restrict__ partials, int rows,
+// bn_finalize_kernel.  Two stages, both in a fixed order (run-to-run reproducible): bn_partials_stage1_kernel folds
+// the rows into RS <= 64 double-precision rows (grid (C/16, RS): a batch-256 launch of the 16-channel layers has 5632
+// rows, one workgroup per 16 channels took 43 us), bn_finalize_partials_kernel folds those and finalizes.
+__global__ __launch_bounds__(256) void bn_partials_stage1_kernel(const float* __restrict__ partials, int rows, int C,
+                                                                 double* __restrict__ out) {
+  __shared__ double sh[16][16][2];
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const int RS = gridDim.y;
+  const int per = (rows + RS - 1) / RS;
+  const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+  double s = 0.0, q = 0.0;
+  if (c < C) {
+    for (int r = r0 + rg; r < r1; r += 16) {
+      const float2 v = *reinterpret_cast<const float2*>(partials + ((long)r * C + c) * 2);
+      s += (double)v.x;
+      q += (double)v.y;
+    }
+  }
+  sh[rg][cl][0] = s; sh[rg][cl][1] = q;
+  __syncthreads();
+  if (rg != 0 || c >= C) return;
+  s = 0.0; q = 0.0;
+  for (int j = 0; j < 16; ++j) { s += sh[j][cl][0]; q += sh[j][cl][1]; }
+  out[((long)blockIdx.y * C + c) * 2] = s;
+  out[((long)blockIdx.y * C + c) * 2 + 1] = q;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_finalize_partials_kernel(const T* __restrict__ partials, int rows,
                                                                    float* running_mean, float* running_var, int64_t* nbt,
                                                                    float* save_mean, float* save_invstd, int C, double count,
                                                                    float momentum, float eps) {
@@ -327,9 +354,8 @@ __global__ __launch_bounds__(256) void bn_finalize_partials_kernel(const float* 
   double s = 0.0, q = 0.0;
   if (c < C) {
     for (int r = rg; r < rows; r += 16) {
-      const float2 v = *reinterpret_cast<const float2*>(partials + ((long)r * C + c) * 2);
-      s += (double)v.x;
-      q += (double)v.y;
+      s += (double)partials[((long)r * C + c) * 2];
+      q += (double)partials[((long)r * C + c) * 2 + 1];
     }
   }
   sh[rg][cl][0] = s; sh[rg][cl][1] = q;
@@ -589,15 +615,25 @@ int mpa_bn_relu_train_fwd(const float* x, const float* gamma, const float* beta,
 
 int mpa_bn_relu_train_fwd_partials(const float* x, const float* partials, int rows, const float* gamma, const float* beta,
                                    float* running_mean, float* running_var, int64_t* num_batches_tracked, float* y,
-                                   float* save_mean, float* save_invstd, int B, int C, int HW, float momentum, float eps,
-                                   int relu, void* stream) {
+                                   float* save_mean, float* save_invstd, double* stage_ws, int B, int C, int HW,
+                                   float momentum, float eps, int relu, void* stream) {
   if (!x || !partials || rows <= 0 || !gamma || !beta || !running_mean || !running_var || !y || !save_mean || !save_invstd)
     return MPA_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  MPA_LAUNCH(bn_finalize_partials_kernel, dim3((unsigned)mpa_cdiv(C, 16)), dim3(256), 0, s, partials, rows, running_mean,
-             running_var, num_batches_tracked, save_mean, save_invstd, C, (double)B * HW, momentum, eps);
-  int rc = mpa_launch_status();
-  if (rc) return rc;
+  int rc;
+  if (rows > 512 && stage_ws) {           // stage_ws: 64 * C * 2 doubles
+    const int RS = (int)std::min<long>(64, mpa_cdiv(rows, 64));
+    MPA_LAUNCH(bn_partials_stage1_kernel, dim3((unsigned)mpa_cdiv(C, 16), (unsigned)RS), dim3(256), 0, s, partials, rows, C,
+               stage_ws);
+    if ((rc = mpa_launch_status()) != MPA_OK) return rc;
+    MPA_LAUNCH(bn_finalize_partials_kernel<double>, dim3((unsigned)mpa_cdiv(C, 16)), dim3(256), 0, s,
+               (const double*)stage_ws, RS, running_mean, running_var, num_batches_tracked, save_mean, save_invstd, C,
+               (double)B * HW, momentum, eps);
+  } else {
+    MPA_LAUNCH(bn_finalize_partials_kernel<float>, dim3((unsigned)mpa_cdiv(C, 16)), dim3(256), 0, s, partials, rows,
+               running_mean, running_var, num_batches_tracked, save_mean, save_invstd, C, (double)B * HW, momentum, eps);
+  }
+  if ((rc = mpa_launch_status()) != MPA_OK) return rc;
   const int chunks = (int)std::max<long>(1, std::min<long>(mpa_cdiv(HW, 1024), 64));
   MPA_LAUNCH(bn_apply_saved_kernel, dim3(B * C, chunks), dim3(256), 0, s, x, gamma, beta, (const float*)save_mean,
              (const float*)save_invstd, y, C, HW, relu);

@@ -322,11 +322,14 @@ class BatchNormReLUFn(torch.autograd.Function):
             # batch statistics from the producing convolution's epilogue: no statistics pass over x
             if partials.shape[1:] != (C, 2):
                 raise RuntimeError(f"batchnorm: partial sums of shape {tuple(partials.shape)} for {C} channels")
+            ws = torch.empty(64 * C * 2, dtype=torch.float64, device=x.device) if partials.shape[0] > 512 else None
             _chk(lib.mpa_bn_relu_train_fwd_partials(_p(x), _p(partials), partials.shape[0], _p(gamma), _p(beta),
                                                    _p(running_mean), _p(running_var),
                                                    ctypes.c_void_p(nbt.data_ptr()) if nbt is not None else None, _p(y),
-                                                   _p(save_mean), _p(save_invstd), B, C, H * W, float(momentum), BN_EPS,
-                                                   int(relu), _s()), "mpa_bn_relu_train_fwd_partials")
+                                                   _p(save_mean), _p(save_invstd),
+                                                   ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, B, C,
+                                                   H * W, float(momentum), BN_EPS, int(relu), _s()),
+                 "mpa_bn_relu_train_fwd_partials")
         elif training:
             ws = torch.empty(2 * C, dtype=torch.float64, device=x.device)
             _chk(lib.mpa_bn_relu_train_fwd(_p(x), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
