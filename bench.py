@@ -359,12 +359,16 @@ def main():
         H, W = dshape[2], dshape[3]
         kflops = dflops * B_loc
         kms = sum(probe_ms) / max(len(probe_ms), 1)
-        # HBM bytes per launch of that kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/);
-        # only valid for the configuration it was collected on
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tfile) and args.config == "SAUnet:L" and B_loc == 256 and args.frames == 75:
-            traffic = json.load(open(tfile))["traffic_bytes"]
+        # HBM bytes per launch of that kernel and its MFMA-pipe busy fraction from separate rocprofv3 --pmc passes
+        # (scratch/pmc_passes.sh -> scratch/pmc_summary.py -> profiles/); only valid for the configuration they were
+        # collected on
+        traffic = mfma_busy = None
+        for tfile in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            tfile = os.path.join(ROOT, "profiles", tfile)
+            if os.path.exists(tfile) and args.config == "SAUnet:L" and B_loc == 256 and args.frames == 75:
+                tj = json.load(open(tfile))
+                traffic, mfma_busy = tj["traffic_bytes"], tj.get("mfma_busy")
+                break
         achieved = kflops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
         out = {
             "metric": "HCQT frames/sec (train step), SAUnet:L" if args.config == "SAUnet:L" else f"HCQT frames/sec (train step), {args.config}",
@@ -380,7 +384,7 @@ def main():
                                       else "not a BASELINE.json configuration"), "global_batch": args.global_batch,
                        "frames": args.frames, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "mfma_busy": mfma_busy,
                          "kernel": f"conv_fwd_kernel {dom.in_channels}->{dom.out_channels} "
                                    f"{dom.kernel_size[0]}x{dom.kernel_size[1]} @{H}x{W} ({dom_name}), local batch {B_loc}",
                          "launch_ms": kms,

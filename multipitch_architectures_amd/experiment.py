@@ -21,7 +21,7 @@ import os
 import numpy as np
 import torch
 
-from . import nn_models
+from . import nn_models, ops
 from .configs import CONFIGS
 from .data_loaders import ContextLoader, dataset_context, dataset_context_segm
 from .losses import BCELoss, PolyphonyLoss
@@ -29,6 +29,7 @@ from .metrics import MEASURES, calculate_eval_measures
 from .metrics.eval_metrics import aggregate_files
 from .metrics.monitoring import early_stopping
 from .optim import AdamW
+from .step import TrainStep
 
 TRAIN_DATASET_PARAMS = {"context": 75, "stride": 50, "compression": 10, "aug:transpsemitones": 5, "aug:randomeq": 20,
                         "aug:noisestd": 1e-4, "aug:tuning": True}
@@ -56,10 +57,12 @@ def build(config, device="cuda:0"):
 
 def train(model, criterion, train_files, val_files, lr=1e-3, max_epochs=100, batch_sizes=(25, 50), seed=0,
           path_trained_model=None, log=logging.info, rank=0, world=1, averager=None, variant="Exp1", stride=None,
-          max_batches=None):
+          max_batches=None, use_graph=True):
     """train_files / val_files: lists of (inputs (6,T,216), targets (T,n_out)) pairs.  Returns the per-epoch history.
     ``variant`` picks the experiment family's stride and per-epoch batch cap (``VARIANTS``); ``stride`` /
-    ``max_batches`` override it."""
+    ``max_batches`` override it.  ``use_graph``: the loop body (forward, loss, backward, AdamW) is captured once as a HIP
+    graph and replayed for every full-size batch (``step.TrainStep``); the last, smaller batch of an epoch and
+    data-parallel runs (``averager``) launch kernel by kernel."""
     var = VARIANTS[variant]
     stride = var["stride"] if stride is None else stride
     max_batches = var["max_batches"] if max_batches is None else max_batches
@@ -75,15 +78,11 @@ def train(model, criterion, train_files, val_files, lr=1e-3, max_epochs=100, bat
     log("\n \n ###################### START TRAINING ###################### \n")
     history = []
     model.train()
+    train_step = TrainStep(model, criterion, optimizer, averager=averager, use_graph=use_graph)
     for epoch in range(max_epochs):
         accum_loss, n_batches = 0.0, 0
         for local_batch, local_labels in train_loader:
-            loss = criterion(model(local_batch), local_labels)
-            optimizer.zero_grad()
-            loss.backward()
-            if averager is not None:
-                averager.finish()
-            optimizer.step()
+            loss = train_step(local_batch, local_labels)     # y_pred = model(x); loss; zero_grad; backward; step
             accum_loss += loss.item()
             n_batches += 1
             if max_batches is not None and n_batches > max_batches:       # RETRAIN_exp180d...py:337-338
@@ -94,6 +93,7 @@ def train(model, criterion, train_files, val_files, lr=1e-3, max_epochs=100, bat
             for local_batch, local_labels in val_loader:
                 accum_val_loss += criterion(model(local_batch), local_labels).item()
                 n_val += 1
+        ops.rng_advance()              # validation ran in train mode (dropout active): move the dropout stream past it
         val_loss = accum_val_loss / max(n_val, 1)
         log("Epoch #" + str(epoch) + " finished. Train Loss: " + "{:.4f}".format(train_loss) + ", Val Loss: " +
             "{:.4f}".format(val_loss) + " with lr: " + "{:.5f}".format(optimizer.param_groups[0]["lr"]))

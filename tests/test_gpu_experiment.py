@@ -52,7 +52,7 @@ def test_exp2_variant_uses_stride_20_and_caps_the_epoch(monkeypatch):
     monkeypatch.setattr(experiment.AdamW, "step", lambda self, *a, **k: (steps.append(1), real_step(self, *a, **k))[1])
     files = [synth_file(frames=3000, seed=1)]
     hist = experiment.train(model, criterion, files, files, max_epochs=2, variant="Exp2", max_batches=3,
-                            log=lambda *_: None)
+                            log=lambda *_: None, use_graph=False)       # kernel-by-kernel: every step calls AdamW.step
     assert seen == [20, 20] and len(hist) == 2
     assert len(steps) == 2 * 4                       # 147 patches at stride 20 = 6 batches of 25 when uncapped
 
