@@ -65,15 +65,16 @@ FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
   // cout blocking: all variants compete; the cost model charges padded couts, operand re-reads, and -- what decides
   // small batches / small images -- the number of *rounds* the grid needs on 256 CUs (a grid of 2112 workgroups on 512
   // resident slots costs 5 rounds, not 4.1)
-  const int nbs[5] = {1, 2, 4, 5, 3};
+  const int nbs[6] = {1, 2, 4, 5, 3, 6};
   const int pbs[6] = {1, 2, 4, 6, 8, 12};
   static const char* force = getenv("MPA_FWD_FORCE");          // diagnostics: "NB,PB" restricts the search
   int fNB = 0, fPB = 0;
   if (force) sscanf(force, "%d,%d", &fNB, &fPB);
-  for (int ni = 0; ni < 5; ++ni) {
+  for (int ni = 0; ni < 6; ++ni) {
     const int NB = nbs[ni];
     if (fNB && NB != fNB) continue;
-    if ((NB == 3) != (phase && phaseX == 3)) continue;      // 48-cout tiles exactly for the 3-phase stores
+    // 48- / 96-cout tiles (16 / 32 channels x 3 phases) exactly for the 3-phase stores
+    if ((NB % 3 == 0) != (phase && phaseX == 3)) continue;
     const int COT = NB * 16;
     const int coTiles = (int)mpa_cdiv(Cout, COT);
     if (ni > 0 && (long)coTiles * COT > (long)mpa_cdiv(Cout, 16) * 16 + 32 && NB > 1) continue;   // too much cout padding
@@ -81,6 +82,7 @@ FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
     for (int pi = 0; pi < 6; ++pi) {
       if ((pbs[pi] == 12 && NB > 2) || (pbs[pi] == 8 && NB > 4)) continue;   // accumulator budget
       if (NB == 3 && (pbs[pi] < 4 || pbs[pi] > 8)) continue;                  // built for PB 4, 6, 8 only
+      if (NB == 6 && pbs[pi] != 4) continue;                                  // 24 accumulator tiles
       const int PB = pbs[pi], P = PB * 64;
       if (fPB && PB != fPB) continue;
       for (int TH = 1; TH <= std::min(OH, P); ++TH) {
@@ -111,7 +113,7 @@ FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
             int CK = 4;
             while (CK < 32 && CK < cin4 && kw * (CK / 4) < 15) CK *= 2;
             int KWS = fwd_kw_special(kw, NB, PB);
-            if ((phase && KWS != 15) || NB == 3) KWS = 0;
+            if ((phase && KWS != 15) || NB % 3 == 0) KWS = 0;
             const int KWP = (kw + 3) & ~3;
             const int cotp = KWS ? COT : COTP;
             auto lds_words = [&](int ck) {
@@ -649,40 +651,44 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
     }
     return;
   }
-  if constexpr (PH && NB == 3) {
-    // stride-(1,3) backward-data with 48-cout tiles: cout' = 3*channel + phase.  All three tiles of a pixel block go
-    // through a wave-private LDS patch; a lane then owns (channel, 4 pixels) = 12 consecutive floats of dx and writes
-    // them as three 16-byte stores (the scalar path scatters 4-byte stores 12 bytes apart).
+  if constexpr (PH && NB % 3 == 0) {
+    // stride-(1,3) backward-data with 48- or 96-cout tiles: cout' = 3*channel + phase, NB / 3 groups of 16 channels.  The
+    // three tiles of a group and pixel block go through a wave-private LDS patch; a lane then owns (channel, 4 pixels)
+    // = 12 consecutive floats of dx and writes them as three 16-byte stores (the scalar path scatters 4-byte stores 12
+    // bytes apart).  96-cout tiles halve the number of workgroups that stage the same dY tile.
     if (!split && p.outXmul == 3 && p.outYmul == 1 && (p.TW & 3) == 0 && (p.OW & 3) == 0 && ((p.outRS * 3) & 3) == 0) {
       __syncthreads();
       float* patch = lds + wave * (48 * 20);           // [cout' 48][pixel 16 (+4 pad)]
       const int cc_l = lane >> 2, quad = lane & 3;
-      const int cc = cot * 16 + cc_l;                  // channel of dx
-      float* yb = p.y + (long)b * p.outBS + (long)cc * p.outCS;
 #pragma unroll
-      for (int pb = 0; pb < PB; ++pb) {
-        const int pix4 = (wave * PB + pb) * 16 + quad * 4;
-        const int pc = pix4 < npix ? pix4 : 0;
-        const int py = pc / p.TW, px = pc - py * p.TW;
-        const int oy = oy0 + py, ox = ox0 + px;
-        const bool ok4 = pix4 < npix && oy < p.OH && ox < p.OW && cc < p.outCdiv;
+      for (int grp = 0; grp < NB / 3; ++grp) {
+        const int cc = cot * (NB / 3) * 16 + grp * 16 + cc_l;      // channel of dx
+        float* yb = p.y + (long)b * p.outBS + (long)cc * p.outCS;
 #pragma unroll
-        for (int nb = 0; nb < 3; ++nb)
+        for (int pb = 0; pb < PB; ++pb) {
+          const int pix4 = (wave * PB + pb) * 16 + quad * 4;
+          const int pc = pix4 < npix ? pix4 : 0;
+          const int py = pc / p.TW, px = pc - py * p.TW;
+          const int oy = oy0 + py, ox = ox0 + px;
+          const bool ok4 = pix4 < npix && oy < p.OH && ox < p.OW && cc < p.outCdiv;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) patch[(nb * 16 + kq * 4 + r) * 20 + l16] = acc[nb][pb][r];
-        __builtin_amdgcn_wave_barrier();
-        float o[12];
+          for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          const float4 t = *reinterpret_cast<const float4*>(patch + (cc_l * 3 + q) * 20 + quad * 4);
-          o[q] = t.x; o[3 + q] = t.y; o[6 + q] = t.z; o[9 + q] = t.w;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (ok4) {
-          float* dst = yb + (long)oy * p.outRS + (long)ox * 3;
-          *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-          *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
-          *reinterpret_cast<float4*>(dst + 8) = make_float4(o[8], o[9], o[10], o[11]);
+            for (int r = 0; r < 4; ++r) patch[(nb * 16 + kq * 4 + r) * 20 + l16] = acc[grp * 3 + nb][pb][r];
+          __builtin_amdgcn_wave_barrier();
+          float o[12];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(patch + (cc_l * 3 + q) * 20 + quad * 4);
+            o[q] = t.x; o[3 + q] = t.y; o[6 + q] = t.z; o[9 + q] = t.w;
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (ok4) {
+            float* dst = yb + (long)oy * p.outRS + (long)ox * 3;
+            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            *reinterpret_cast<float4*>(dst + 8) = make_float4(o[8], o[9], o[10], o[11]);
+          }
         }
       }
       return;
@@ -827,9 +833,16 @@ int launch_fwd_nb3(const FwdPlan& pl, const ConvFwdParams& p, hipStream_t s) {  
   }
 }
 
+int launch_fwd_nb6(const FwdPlan& pl, const ConvFwdParams& p, hipStream_t s) {      // 96-cout phase tiles
+  dim3 grid((unsigned)(mpa_cdiv(p.nTilesAll, 8) * 8 * pl.coTiles), 1, (unsigned)mpa_cdiv(pl.nChunks, p.chunksPer));
+  if (pl.KWS != 0 || p.outCdiv >= p.Cout || pl.PB != 4) return MPA_ERR_UNSUPPORTED;
+  return launch_fwd_ef<6, 4, 0, false, true>(pl, p, grid, s);
+}
+
 int launch_fwd(const FwdPlan& pl, const ConvFwdParams& p, hipStream_t s) {
   switch (pl.NB) {
     case 3: return launch_fwd_nb3(pl, p, s);
+    case 6: return launch_fwd_nb6(pl, p, s);
     case 1: return launch_fwd_nb<1>(pl, p, s);
     case 2: return launch_fwd_nb<2>(pl, p, s);
     case 4: return launch_fwd_nb<4>(pl, p, s);
