@@ -1977,7 +1977,7 @@ static int conv_fwd_impl(int B, int Cin, int H, int W, int Cout, int kh, int kw,
     static const int sk_env = getenv("MPA_FWD_SK") ? atoi(getenv("MPA_FWD_SK")) : 1;      // diagnostics: 0 = off
     const long vblocks = mpa_cdiv(p.nTilesAll, 8) * 8 * pl.coTiles;
     const double xcu = (double)vblocks / 256.0;
-    if (sk_env && allow_split && pl.KS == 1 && act == MPA_ACT_NONE && !bias && !stats && pl.nChunks >= 8 && xcu < 12.0 &&
+    if (sk_env && allow_split && pl.KS == 1 && act == MPA_ACT_NONE && !bias && !stats && pl.nChunks >= 4 && xcu < 12.0 &&
         std::ceil(xcu) / xcu > 1.05 && vblocks * pl.nChunks < 0x7fffffffL) {
       p.sk_units = (int)(vblocks * pl.nChunks);
       if (mpa_zero_async(y, sizeof(float) * (size_t)B * (size_t)outBS, s) != MPA_OK) return MPA_ERR_LAUNCH;
