@@ -798,10 +798,15 @@ int launch_fwd_ef(const FwdPlan& pl, const ConvFwdParams& p, dim3 grid, hipStrea
   }
   if (p.sk_units > 0) {
     // stream-K launch: exactly the resident workgroups (occupancy API, per instantiation and LDS size)
-    int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)conv_fwd_kernel<NB, PB, KW, EF, PH>, 256,
-                                                     pl.lds_bytes) != hipSuccess || occ < 1)
-      occ = 1;
+    static int occ_cache[164] = {0};               // per instantiation, by LDS KiB (queried once, outside any capture cost)
+    const size_t kib = std::min<size_t>(pl.lds_bytes >> 10, 163);
+    int occ = occ_cache[kib];
+    if (occ == 0) {
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)conv_fwd_kernel<NB, PB, KW, EF, PH>, 256,
+                                                       pl.lds_bytes) != hipSuccess || occ < 1)
+        occ = 1;
+      occ_cache[kib] = occ;
+    }
     static const int occ_env = getenv("MPA_SK_OCC") ? atoi(getenv("MPA_SK_OCC")) : 0;      // diagnostics
     if (occ_env > 0) occ = occ_env;
     const int G = 256 * std::min(occ, 4);
