@@ -41,7 +41,8 @@ def main():
     ap.add_argument("--frames", type=int, default=1500)
     ap.add_argument("--variant", default="Exp1", choices=sorted(experiment.VARIANTS),
                     help="Exp1: stride 50, whole epochs; Exp2 ('moresamples'/RETRAIN scripts): stride 20, epochs capped "
-                         "after n_batches > 3800")
+                         "after n_batches > 3800; Exp3 (Schubert splits): stride 10; Exp4 ('bigmix'): stride 35 + cap "
+                         "(per-dataset strides: experiment.EXP4_STRIDES, passed per recording through the API)")
     ap.add_argument("--out", default=None, help="path of the best-model checkpoint (bare state_dict, as the scripts save it)")
     args = ap.parse_args()
     logging.basicConfig(level=logging.INFO, format="%(message)s")

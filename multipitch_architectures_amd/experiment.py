@@ -42,7 +42,15 @@ EVAL_THRESH = 0.4
 #   Exp1 (Section IV-B)        stride 50 for train / val, whole epochs                       exp180d...py:38-50
 #   Exp2 (Section IV-C, "moresamples" / RETRAIN*)  stride 20 and an epoch ends after the batch that makes
 #        n_batches > 3800, i.e. after at most 3801 batches                                   RETRAIN_exp180d...py:38-50,337-338
-VARIANTS = {"Exp1": {"stride": 50, "max_batches": None}, "Exp2": {"stride": 20, "max_batches": 3800}}
+#   Exp3 (Section IV-D, Schubert Winterreise splits)  stride 10, whole epochs                exp200a...py:38-50
+#   Exp4 (Section IV-E, "bigmix": five training datasets concatenated)  a stride per dataset and the 3800-batch cap
+#        (exp210d...py:38-50, 310-311, 359-360, 405, 437-438, 535): pass (inputs, targets, stride) triples as files --
+#        a third element overrides the variant's stride for that recording; EXP4_STRIDES holds the scripts' values
+VARIANTS = {"Exp1": {"stride": 50, "max_batches": None}, "Exp2": {"stride": 20, "max_batches": 3800},
+            "Exp3": {"stride": 10, "max_batches": None}, "Exp4": {"stride": 35, "max_batches": 3800}}
+# dataset -> (train stride, validation stride; None: the dataset has no validation part)
+EXP4_STRIDES = {"MusicNet": (35, 35), "Schubert_Winterreise": (6, 4), "Bach10": (1, 1), "PHENICX-Anechoic": (2, None),
+                "ChoralSingingDataset": (4, 4)}
 
 
 def build(config, device="cuda:0"):
@@ -58,7 +66,7 @@ def build(config, device="cuda:0"):
 def train(model, criterion, train_files, val_files, lr=1e-3, max_epochs=100, batch_sizes=(25, 50), seed=0,
           path_trained_model=None, log=logging.info, rank=0, world=1, averager=None, variant="Exp1", stride=None,
           max_batches=None, use_graph=True):
-    """train_files / val_files: lists of (inputs (6,T,216), targets (T,n_out)) pairs.  Returns the per-epoch history.
+    """train_files / val_files: lists of (inputs (6,T,216), targets (T,n_out)[, stride]) tuples.  Returns the per-epoch history.
     ``variant`` picks the experiment family's stride and per-epoch batch cap (``VARIANTS``); ``stride`` /
     ``max_batches`` override it.  ``use_graph``: the loop body (forward, loss, backward, AdamW) is captured once as a HIP
     graph and replayed for every full-size batch (``step.TrainStep``); the last, smaller batch of an epoch and
@@ -66,9 +74,10 @@ def train(model, criterion, train_files, val_files, lr=1e-3, max_epochs=100, bat
     var = VARIANTS[variant]
     stride = var["stride"] if stride is None else stride
     max_batches = var["max_batches"] if max_batches is None else max_batches
-    train_sets = [dataset_context(i, t, dict(TRAIN_DATASET_PARAMS, stride=stride), seed=seed + k)
-                  for k, (i, t) in enumerate(train_files)]
-    val_sets = [dataset_context(i, t, dict(VAL_DATASET_PARAMS, stride=stride)) for i, t in val_files]
+    own = lambda f: f[2] if len(f) > 2 and f[2] is not None else stride         # per-recording stride (Exp4)
+    train_sets = [dataset_context(f[0], f[1], dict(TRAIN_DATASET_PARAMS, stride=own(f)), seed=seed + k)
+                  for k, f in enumerate(train_files)]
+    val_sets = [dataset_context(f[0], f[1], dict(VAL_DATASET_PARAMS, stride=own(f))) for f in val_files]
     train_loader = ContextLoader(train_sets, batch_sizes[0], shuffle=True, seed=seed, rank=rank, world=world)
     val_loader = ContextLoader(val_sets, batch_sizes[1], shuffle=False)
     optimizer = AdamW(model.parameters(), lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, amsgrad=False)

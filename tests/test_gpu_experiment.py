@@ -43,6 +43,9 @@ def test_exp2_variant_uses_stride_20_and_caps_the_epoch(monkeypatch):
     from multipitch_architectures_amd.synth import synth_file
     assert experiment.VARIANTS["Exp2"] == {"stride": 20, "max_batches": 3800}
     assert experiment.VARIANTS["Exp1"] == {"stride": 50, "max_batches": None}
+    assert experiment.VARIANTS["Exp3"] == {"stride": 10, "max_batches": None}
+    assert experiment.VARIANTS["Exp4"] == {"stride": 35, "max_batches": 3800}
+    assert experiment.EXP4_STRIDES["Schubert_Winterreise"] == (6, 4) and experiment.EXP4_STRIDES["PHENICX-Anechoic"] == (2, None)
     torch.manual_seed(0)
     model, criterion, cfg = experiment.build("tiny:CNN")
     seen, steps = [], []
@@ -54,7 +57,13 @@ def test_exp2_variant_uses_stride_20_and_caps_the_epoch(monkeypatch):
     hist = experiment.train(model, criterion, files, files, max_epochs=2, variant="Exp2", max_batches=3,
                             log=lambda *_: None, use_graph=False)       # kernel-by-kernel: every step calls AdamW.step
     assert seen == [20, 20] and len(hist) == 2
-    assert len(steps) == 2 * 4                       # 147 patches at stride 20 = 6 batches of 25 when uncapped
+    # Exp4: a stride per recording (third tuple element) overrides the variant's
+    seen.clear()
+    inp, tgt = files[0]
+    experiment.train(model, criterion, [(inp, tgt, 6), (inp, tgt)], [(inp, tgt, 4)], max_epochs=1, variant="Exp4",
+                     max_batches=1, log=lambda *_: None, use_graph=False)
+    assert seen == [6, 35, 4]
+    assert len(steps) == 2 * 4 + 2                       # 147 patches at stride 20 = 6 batches of 25 when uncapped
 
 
 @pytest.mark.parametrize("name", ["tiny:CNN", "tiny:DRCNN", "tiny:Unet"])
