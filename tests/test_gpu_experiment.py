@@ -99,3 +99,39 @@ def test_segment_wise_inference(name):
     # the runner's test() accepts the switch and produces the same measures layout
     mean, _ = experiment.test(model, [(inputs, targets)], ["f"], log=lambda *_: None, segment=L)
     assert set(mean) == set(experiment.MEASURES)
+
+
+@pytest.mark.parametrize("name", ["tiny:CNN", "tiny:Unet", "tiny:SAUnet"])
+def test_file_evaluation_matches_the_oracle_chain(name):
+    """The scripts' test flow for one recording (exp126a...py:415-470: pad half a context, one 75-frame patch per frame in
+    batches of 50, threshold 0.4, calculate_eval_measures) through the HIP path against the same chain built from the CPU
+    oracle (oracle/restate.py on the patches, oracle/restate_metrics.py on its predictions) -- SURVEY 8(d)'s stand-in for
+    the F-score on MuN-10, which needs data that is not in the reference: predictions within 1e-4, equal argmax pitch per
+    frame, equal thresholded activations, and therefore the same precision / recall / F-measure."""
+    from helpers import oracle_forward
+    from multipitch_architectures_amd import experiment, nn_models
+    from multipitch_architectures_amd.configs import CONFIGS
+    from multipitch_architectures_amd.metrics import MEASURES, calculate_eval_measures
+    from multipitch_architectures_amd.synth import det_fill, synth_file
+    from oracle import restate_metrics
+    dev = torch.device("cuda:0")
+    cfg = CONFIGS[name]
+    model = getattr(nn_models, cfg["cls"])(**cfg["kwargs"])
+    model.load_state_dict(det_fill(model.state_dict()))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(dev).eval()
+    inputs, targets = synth_file(frames=130, seed=9)
+    pred = experiment.predict_file(model, inputs, targets).cpu()
+    got = calculate_eval_measures(torch.from_numpy(targets), pred, MEASURES, threshold=0.4)
+    padded = np.pad(inputs, ((0, 0), (37, 38), (0, 0)))
+    X = torch.from_numpy(np.stack([np.log(1.0 + 10.0 * padded[:, i:i + 75]) for i in range(130)]).astype(np.float32))
+    with torch.no_grad():                               # batches of 50 consecutive frames, as the reference's DataLoader
+        ref = torch.cat([oracle_forward(name, sd, X[i:i + 50], train=False) for i in range(0, 130, 50)])[:, 0, 0]
+    assert float((pred - ref).abs().max()) <= 1e-4
+    assert torch.equal(pred.argmax(1), ref.argmax(1))
+    assert torch.equal(pred >= 0.4, ref >= 0.4)
+    want = restate_metrics.all_measures(targets, ref.numpy(), threshold=0.4, use_sklearn=False)
+    for m in ("precision", "recall", "f_measure", "binary_accuracy"):
+        assert got[m] == pytest.approx(want[m], abs=1e-12), m
+    for m in MEASURES:
+        assert got[m] == pytest.approx(want[m], rel=2e-4, abs=1e-6), m
