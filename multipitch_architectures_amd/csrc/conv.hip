@@ -389,10 +389,6 @@ struct ConvFwdParams {
   int chunksPer;       // input-channel chunks per blockIdx.z slice (== nChunks when the channels are not split)
   int coTiles, nTilesAll;   // cout tiles; pixel tiles over the whole batch
   float* stats;             // BatchNorm fusion: per-(pixel tile, cout) partial sums of y and y^2 -> [nTilesAll][Cout][2]
-  // stream-K (backward-data of small grids): the launch's (tile, channel chunk) units are dealt evenly to a grid of
-  // exactly the resident workgroups; a workgroup's range may start and end inside a tile, such pieces add atomically
-  int sk_upw;               // units per workgroup (0 = one tile or channel slice per workgroup, as planned)
-  int sk_units;             // virtual blocks x channel chunks
 };
 
 // The one quad per row that straddles the right limit `xend` of the readable columns is skipped by the 16-byte stager;
@@ -438,17 +434,16 @@ __device__ __forceinline__ void edge_fix_store(const EdgeFix& f, float* __restri
 // ------------------------------------------------------------------------------------------------ forward kernel
 // PH (phase stores): backward-data variants whose couts are (channel, x/y phase) pairs -- a separate instantiation, as
 // EF is: the 16->128 forward sits on a register cliff and lost 10 % whenever either was compiled into the common kernel
-// one (pixel tile, cout tile) of the launch, input-channel chunks [c_begin, c_end): `w` is the virtual block index
-// (blockIdx.x of an ordinary launch), `split` says that other pieces add into the same outputs (atomic epilogue)
-template <int NB, int PB, int KW, bool EF, bool PH>
-__device__ __forceinline__ void conv_fwd_body(const ConvFwdParams& p, float* lds, const int w, const int c_begin, const int c_end,
-                                              const bool split) {
+template <int NB, int PB, int KW = 0, bool EF = false, bool PH = false>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lds_in = lds;
   float* lds_w0 = lds + p.IN64;          // two filter-slab buffers: slab dy+1 streams in while dy is consumed
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so workgroup w runs
   // on XCD w%8 as the (w/8)-th of that XCD.  The coTiles workgroups that read the same input tile are made consecutive
   // *within one XCD*: the tile is fetched from HBM once and hit in that L2 by the others.
+  const int w = blockIdx.x;
   const int seq = w >> 3;
   const int cot = seq % p.coTiles;
   int bid = (seq / p.coTiles) * 8 + (w & 7);
@@ -496,6 +491,8 @@ __device__ __forceinline__ void conv_fwd_body(const ConvFwdParams& p, float* lds
 
   EdgeFix efix;            // only live in the EF instantiations
   (void)efix;
+  const bool split = gridDim.z > 1;
+  const int c_begin = blockIdx.z * p.chunksPer, c_end = min(p.nChunks, c_begin + p.chunksPer);
   for (int c = c_begin; c < c_end; ++c) {
     __syncthreads();   // every wave is done with the previous chunk's tile and slabs
     const bool do_stage = (p.dbg != 1 && p.dbg != 3) || c == c_begin;
@@ -748,7 +745,7 @@ __device__ __forceinline__ void conv_fwd_body(const ConvFwdParams& p, float* lds
         const int co = cot * p.COT + nb * 16 + kq * 4 + r;
         if (co >= p.Cout) continue;
         float v = acc[nb][pb][r];
-        if (p.bias && c_begin == 0) v += p.bias[co];
+        if (p.bias && blockIdx.z == 0) v += p.bias[co];
         float* dst;
         if constexpr (!PH) {                  // plain NCHW store
           dst = p.y + (long)b * p.outBS + (long)co * p.outCS + (long)oy * p.outRS + ox;
@@ -769,25 +766,6 @@ __device__ __forceinline__ void conv_fwd_body(const ConvFwdParams& p, float* lds
   }
 }
 
-template <int NB, int PB, int KW = 0, bool EF = false, bool PH = false>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  if (p.sk_upw > 0) {
-    // stream-K: this workgroup's contiguous range of (virtual block, chunk) units, tile by tile
-    int u = blockIdx.x * p.sk_upw;
-    const int u1 = min(p.sk_units, u + p.sk_upw);
-    while (u < u1) {
-      const int w = u / p.nChunks, c0 = u - w * p.nChunks;
-      const int c1 = min(p.nChunks, c0 + (u1 - u));
-      conv_fwd_body<NB, PB, KW, EF, PH>(p, lds, w, c0, c1, !(c0 == 0 && c1 == p.nChunks));
-      u += c1 - c0;
-    }
-    return;
-  }
-  const int c_begin = blockIdx.z * p.chunksPer;
-  conv_fwd_body<NB, PB, KW, EF, PH>(p, lds, blockIdx.x, c_begin, min(p.nChunks, c_begin + p.chunksPer), gridDim.z > 1);
-}
-
 template <int NB, int PB, int KW, bool EF, bool PH = false>
 int launch_fwd_ef(const FwdPlan& pl, const ConvFwdParams& p, dim3 grid, hipStream_t s) {
   static bool big_lds = false;
@@ -795,26 +773,6 @@ int launch_fwd_ef(const FwdPlan& pl, const ConvFwdParams& p, dim3 grid, hipStrea
     (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<NB, PB, KW, EF, PH>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               80 * 1024);
     big_lds = true;
-  }
-  if (p.sk_units > 0) {
-    // stream-K launch: exactly the resident workgroups (occupancy API, per instantiation and LDS size)
-    static int occ_cache[164] = {0};               // per instantiation, by LDS KiB (queried once, outside any capture cost)
-    const size_t kib = std::min<size_t>(pl.lds_bytes >> 10, 163);
-    int occ = occ_cache[kib];
-    if (occ == 0) {
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)conv_fwd_kernel<NB, PB, KW, EF, PH>, 256,
-                                                       pl.lds_bytes) != hipSuccess || occ < 1)
-        occ = 1;
-      occ_cache[kib] = occ;
-    }
-    static const int occ_env = getenv("MPA_SK_OCC") ? atoi(getenv("MPA_SK_OCC")) : 0;      // diagnostics
-    if (occ_env > 0) occ = occ_env;
-    const int G = 256 * std::min(occ, 4);
-    ConvFwdParams q = p;
-    q.sk_upw = (int)mpa_cdiv(p.sk_units, G);
-    dim3 g2((unsigned)mpa_cdiv(p.sk_units, q.sk_upw), 1, 1);
-    MPA_LAUNCH((conv_fwd_kernel<NB, PB, KW, EF, PH>), g2, dim3(256), pl.lds_bytes, s, q);
-    return mpa_launch_status();
   }
   MPA_LAUNCH((conv_fwd_kernel<NB, PB, KW, EF, PH>), grid, dim3(256), pl.lds_bytes, s, p);
   return mpa_launch_status();
@@ -1975,20 +1933,6 @@ static int conv_fwd_impl(int B, int Cin, int H, int W, int Cout, int kh, int kw,
   p.chunksPer = (int)mpa_cdiv(pl.nChunks, pl.KS);
   p.coTiles = pl.coTiles; p.nTilesAll = B * pl.tilesY * pl.tilesX;
   p.stats = stats;
-  // Stream-K for backward-data launches whose tile count leaves the busiest CU with a visibly larger share (704 tiles on
-  // 256 CUs are 2.75 per CU: 3): (tile, chunk) units are dealt evenly to exactly the resident workgroups and the pieces
-  // of a tile add atomically into the zeroed output -- same arithmetic as the channel-split launch, finer grain.
-  {
-    static const int sk_env = getenv("MPA_FWD_SK") ? atoi(getenv("MPA_FWD_SK")) : 1;      // diagnostics: 0 = off
-    const long vblocks = mpa_cdiv(p.nTilesAll, 8) * 8 * pl.coTiles;
-    const double xcu = (double)vblocks / 256.0;
-    if (sk_env && allow_split && pl.KS == 1 && act == MPA_ACT_NONE && !bias && !stats && pl.nChunks >= 4 && xcu < 12.0 &&
-        std::ceil(xcu) / xcu > 1.05 && vblocks * pl.nChunks < 0x7fffffffL) {
-      p.sk_units = (int)(vblocks * pl.nChunks);
-      if (mpa_zero_async(y, sizeof(float) * (size_t)B * (size_t)outBS, s) != MPA_OK) return MPA_ERR_LAUNCH;
-      return launch_fwd(pl, p, s);
-    }
-  }
   if (mpa_cdiv(pl.nChunks, p.chunksPer) <= 1) return launch_fwd(pl, p, s);
   // channel-split launch: slices add into a zeroed output, the activation (if any) runs afterwards in place
   if (mpa_zero_async(y, sizeof(float) * (size_t)B * (size_t)outBS, s) != MPA_OK) return MPA_ERR_LAUNCH;
