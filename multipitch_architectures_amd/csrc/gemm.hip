@@ -301,7 +301,7 @@ int gemm_impl(GemmParams p, int nbatch, int shared_c, hipStream_t s) {
   for (int v = 0; v < 4; ++v) {
     const long blocks = mpa_cdiv(M, TM[v]) * mpa_cdiv(N, TN[v]);
     // padding waste of partial tiles is paid in full
-    for (int sp = 1; sp <= 32; sp *= 2) {
+    for (int sp = 1; sp <= 32; ++sp) {             // every split count: 72 tiles x 7 splits fill 504 of 512 slots, x 8 need two rounds
       if (sp > 1 && (act != MPA_ACT_NONE || K / sp < 256)) break;
       const double rounds = (double)mpa_cdiv(blocks * sp * nbatch, 512);
       const double cost = rounds * ((double)mpa_cdiv(K, sp) + 96.0) * TM[v] * TN[v] / EFF[v] * (sp > 1 ? 1.03 : 1.0);
