@@ -119,3 +119,21 @@ def test_every_family_captures_and_trains(dev, name):
     assert all(torch.isfinite(p).all() for p in pg)
     le, _, _, _ = _run(dev, name, False, 2, B=4)
     np.testing.assert_allclose(lg[:2], le, rtol=1e-4)               # step 1 is the first replay
+
+
+def test_eager_forward_after_replays_sees_the_updated_weights(dev):
+    """the packed filter banks are cached per weight version; graph replays change the weights behind PyTorch's back,
+    so TrainStep bumps the parameter epoch after every replay -- an eval forward right after training must use the
+    current weights (checked against the oracle run on the model's current state_dict)"""
+    from helpers import oracle_forward
+    _, _, ts, _ = _run(dev, "tiny:Unet", True, 5, B=4)
+    model = ts.model
+    assert ts.replays == 4
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    model.eval()
+    x, _ = synth_batch(3, 75, seed=31)
+    with torch.no_grad():
+        got = model(x.to(dev)).cpu()
+        ref = oracle_forward("tiny:Unet", sd, x, train=False)
+    assert float((got - ref).abs().max()) <= 1e-4
+    model.train()
