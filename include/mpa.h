@@ -33,6 +33,7 @@ extern "C" {
 #define MPA_ACT_RELU 1
 #define MPA_ACT_LRELU 2
 #define MPA_ACT_SIGMOID 3
+#define MPA_ACT_ELU 4       /* nn.ELU(alpha=1): x > 0 ? x : exp(x) - 1  (double_conv alt_order, unet_cnns.py:60-70) */
 
 const char* mpa_strerror(int code);
 int mpa_version(void);

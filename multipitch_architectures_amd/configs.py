@@ -67,6 +67,8 @@ CONFIGS = {
                       num_heads=8, mlp_dim=64, pos_encoding="sinusoidal"),
     "tiny:SAUnet-res": _c("simple_u_net_doubleselfattn", n_chan_layers=[8, 8, 6, 4], scalefac=16, embed_dim=32,
                           num_heads=4, mlp_dim=48, pos_encoding=None, residual=True),
+    "tiny:SAUnet-alt": _c("simple_u_net_doubleselfattn", n_chan_layers=[8, 8, 6, 4], scalefac=16, embed_dim=32,
+                          num_heads=4, mlp_dim=48, pos_encoding=None, alt_order=True, residual=True),
     "tiny:SAUSnet": _c("simple_u_net_doubleselfattn_twolayers", n_chan_layers=[8, 8, 6, 4], scalefac=16,
                        embed_dim=32, num_heads=8, mlp_dim=64, pos_encoding="sinusoidal"),
     "tiny:BLUnet": _c("u_net_blstm_varlayers", n_chan_layers=[8, 8, 6, 4], scalefac=16, embed_dim=416,

@@ -52,6 +52,7 @@ __device__ __forceinline__ float mpa_apply_act(float v, int act, float slope) {
     case MPA_ACT_RELU: return v > 0.f ? v : 0.f;
     case MPA_ACT_LRELU: return v >= 0.f ? v : v * slope;
     case MPA_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+    case MPA_ACT_ELU: return v > 0.f ? v : expm1f(v);
     default: return v;
   }
 }

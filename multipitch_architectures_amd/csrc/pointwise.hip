@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
       case MPA_ACT_RELU: r = v > 0.f ? g : 0.f; break;
       case MPA_ACT_LRELU: r = v >= 0.f ? g : g * slope; break;
       case MPA_ACT_SIGMOID: r = g * v * (1.f - v); break;
+      case MPA_ACT_ELU: r = v > 0.f ? g : g * (v + 1.f); break;      // v = y: y <= 0 <=> x <= 0, dy/dx = exp(x) = y + 1
       default: r = g;
     }
     dx[i] = r;

@@ -189,6 +189,17 @@ class Sigmoid(_Pointwise):
     act = ops.ACT_SIGMOID
 
 
+class ELU(_Pointwise):
+    """nn.ELU(alpha=1.0) -- double_conv's alt_order branch (unet_cnns.py:60-70)"""
+    act = ops.ACT_ELU
+
+    def __init__(self, alpha=1.0, inplace=False):
+        super().__init__()
+        if alpha != 1.0:
+            raise NotImplementedError("only nn.ELU(alpha=1.0), the value the reference uses, is built")
+        self.alpha = alpha
+
+
 class Dropout(nn.Module):
     def __init__(self, p=0.5):
         super().__init__()

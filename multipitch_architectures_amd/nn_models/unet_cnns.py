@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from .. import ops
 from .basic_cnns import _head
-from .layers import (BatchNorm2d, Conv2d, ConvActPoolDrop, Dropout, LayerNorm, LeakyReLU, Linear, LSTM, MaxPool2d,
+from .layers import (BatchNorm2d, Conv2d, ConvActPoolDrop, Dropout, ELU, LayerNorm, LeakyReLU, Linear, LSTM, MaxPool2d,
                      MultiheadAttention, ReLU)
 
 
@@ -35,6 +35,16 @@ class _DoubleConvSeq(nn.Sequential):
         return h
 
 
+class _AltOrderSeq(nn.Sequential):
+    """ELU -> BN -> Dropout -> Conv, twice (double_conv(alt_order=True)); BatchNorm without the fused ReLU."""
+
+    def forward(self, x):
+        h = x
+        for m in self:
+            h = m(h, relu=False) if isinstance(m, BatchNorm2d) else m(h)
+        return h
+
+
 class double_conv(nn.Module):
     """ Two convolutional layers, each followed by batch normalization and ReLU  (unet_cnns.py:30-82)"""
 
@@ -45,10 +55,13 @@ class double_conv(nn.Module):
         self.out_channels = out_channels
         if not mid_channels:
             mid_channels = out_channels
-        if alt_order:
-            raise NotImplementedError("double_conv(alt_order=True) (ELU-BN-Dropout-Conv, unet_cnns.py:60-70) is not used "
-                                      "by any experiment and is not built yet")
-        if convdrop is None:      # unet_cnns.py:40-48: no Dropout slots -> Sequential indices 0,1,3,4
+        if alt_order:             # unet_cnns.py:60-70: ELU, BN, Dropout, Conv, twice -> Sequential indices 1, 3, 5, 7
+            self.double_conv = _AltOrderSeq(
+                ELU(alpha=1.0, inplace=False), BatchNorm2d(in_channels), Dropout(p=convdrop),
+                Conv2d(in_channels, mid_channels, kernel_size=kernel_size, padding=padding),
+                ELU(alpha=1.0, inplace=False), BatchNorm2d(mid_channels), Dropout(p=convdrop),
+                Conv2d(mid_channels, out_channels, kernel_size=kernel_size, padding=padding))
+        elif convdrop is None:      # unet_cnns.py:40-48: no Dropout slots -> Sequential indices 0,1,3,4
             self.double_conv = _DoubleConvSeq(
                 Conv2d(in_channels, mid_channels, kernel_size=kernel_size, padding=padding),
                 BatchNorm2d(mid_channels), ReLU(inplace=True),

@@ -13,7 +13,7 @@ import torch
 from . import _lib as L
 from ._lib import ConvDesc
 
-ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_ELU = 0, 1, 2, 3, 4
 BN_EPS = 1e-5
 LN_EPS = 1e-5
 

@@ -40,7 +40,8 @@ for _name in ("tiny:CNN", "tiny:DRCNN", "tiny:Unet", "tiny:SAUnet", "tiny:SAUnet
               "tiny:BLUnet", "tiny:PUnet"):
     CASES += [(_name, 1, 75, False), (_name, 2, 75, True), (_name, 8, 75, False), (_name, 2, 174, False)]
 CASES += [("tiny:SAUnet", 25, 75, True), ("tiny:SAUnet", 50, 75, False), ("tiny:Unet", 3, 100, True)]
-CASES += [("tiny:Unet", 32, 75, True)]      # BatchNorm over 32 patches is not chaotic: a tight whole-model gradient check
+CASES += [("tiny:Unet", 32, 75, True)]
+CASES += [("tiny:SAUnet-alt", 2, 75, True), ("tiny:SAUnet-alt", 3, 100, False)]     # double_conv(alt_order=True): ELU-BN-Dropout-Conv      # BatchNorm over 32 patches is not chaotic: a tight whole-model gradient check
 CASES += [
     ("CNN:XS", 8, 75, True), ("CNN:XS", 8, 174, False),        # BASELINE.json configs[0]
     ("DRCNN:L", 1, 75, False),

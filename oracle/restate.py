@@ -106,9 +106,18 @@ def upconcat(x1, x2):
     return torch.cat([x2, x1], dim=1)
 
 
-def double_conv(x, sd, prefix, pad, train, residual=False, convdrop=0):
-    """double_conv default branch (unet_cnns.py:49-59): conv 0, BN 1, ReLU, Drop, conv 4, BN 5, ReLU, Drop."""
+def double_conv(x, sd, prefix, pad, train, residual=False, convdrop=0, alt_order=False):
+    """double_conv default branch (unet_cnns.py:49-59): conv 0, BN 1, ReLU, Drop, conv 4, BN 5, ReLU, Drop;
+    alt_order (unet_cnns.py:60-70): ELU 0, BN 1, Drop, conv 3, ELU 4, BN 5, Drop, conv 7."""
     p = prefix + ".double_conv"
+    if alt_order:
+        h = dropout(batchnorm2d(F.elu(x), sd, p + ".1", train), convdrop, train)
+        h = conv(h, sd, p + ".3", padding=pad)
+        h = dropout(batchnorm2d(F.elu(h), sd, p + ".5", train), convdrop, train)
+        h = conv(h, sd, p + ".7", padding=pad)
+        if residual:
+            h = conv(x, sd, prefix + ".resize") + h
+        return h
     h = conv(x, sd, p + ".0", padding=pad)
     h = dropout(torch.relu(batchnorm2d(h, sd, p + ".1", train)), convdrop, train)
     h = conv(h, sd, p + ".4", padding=pad)
@@ -238,10 +247,10 @@ _UNET_K = {"inc": 7, "down1.1": 7, "down2.1": 4, "down3.1": 2, "down4.1": 1,
            "upconv1": 1, "upconv2": 2, "upconv3": 4, "upconv4": 7}
 
 
-def _unet(sd, x, train, taps, a_lrelu, p_dropout, convdrop=0, residual=False, bottleneck=None, skip4=None):
+def _unet(sd, x, train, taps, a_lrelu, p_dropout, convdrop=0, residual=False, bottleneck=None, skip4=None, alt_order=False):
     """Shared trunk of simple_u_net_largekernels and its descendants (unet_cnns.py:395-407)."""
     t = taps if taps is not None else {}
-    dc = lambda h, name, res: double_conv(h, sd, name, (_UNET_K[name],) * 2, train, res, convdrop)
+    dc = lambda h, name, res: double_conv(h, sd, name, (_UNET_K[name],) * 2, train, res, convdrop, alt_order)
     h = layernorm_cf(x, sd["layernorm.weight"], sd["layernorm.bias"])
     t["x_norm"] = h
     x1 = dc(h, "inc", False)
@@ -272,12 +281,12 @@ def simple_u_net_largekernels(sd, x, train=False, taps=None, a_lrelu=0.3, p_drop
 
 
 def simple_u_net_doubleselfattn(sd, x, train=False, taps=None, a_lrelu=0.3, p_dropout=0.2, convdrop=0,
-                                residual=False, num_heads=8, pos_encoding=None, **_):
+                                residual=False, num_heads=8, pos_encoding=None, alt_order=False, **_):
     """unet_cnns.py:559-575.  attention1/2 are built with the *default* p_dropout=0.2 (:528-529)."""
     def bott(x5):
         x5 = transformer_enc_layer(x5, sd, "attention1", num_heads, train, 0.2, pos_encoding)
         return transformer_enc_layer(x5, sd, "attention2", num_heads, train, 0.2, None)
-    return _unet(sd, x, train, taps, a_lrelu, p_dropout, convdrop, residual, bottleneck=bott)[0]
+    return _unet(sd, x, train, taps, a_lrelu, p_dropout, convdrop, residual, bottleneck=bott, alt_order=alt_order)[0]
 
 
 def simple_u_net_doubleselfattn_twolayers(sd, x, train=False, taps=None, a_lrelu=0.3, p_dropout=0.2, convdrop=0,

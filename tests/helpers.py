@@ -73,7 +73,7 @@ def _saunet_p0(sd, x, train, taps, kw):
         x5 = restate.transformer_enc_layer(x5, sd, "attention1", kw["num_heads"], train, 0.0, kw.get("pos_encoding"))
         return restate.transformer_enc_layer(x5, sd, "attention2", kw["num_heads"], train, 0.0, None)
     return restate._unet(sd, x, train, taps, kw["a_lrelu"], 0.0, kw.get("convdrop", 0), kw.get("residual", False),
-                         bottleneck=bott)[0]
+                         bottleneck=bott, alt_order=kw.get("alt_order", False))[0]
 
 
 def oracle_loss(name, res, y):

@@ -351,6 +351,21 @@ def test_bce_and_ce(dev):
     _close(bgp.grad, b.grad, 1e-5)
 
 
+def test_elu_activation(dev):
+    """nn.ELU(alpha=1) of double_conv(alt_order=True) (unet_cnns.py:60-70): forward and backward vs torch in float64"""
+    from multipitch_architectures_amd import ops
+    x = _rand((3, 5, 17, 33), 8, 2.0)
+    xr = x.double().requires_grad_(True)
+    ref = F.elu(xr)
+    g = _rand(tuple(x.shape), 9)
+    ref.backward(g.double())
+    xg = x.to(dev).requires_grad_(True)
+    y = ops.activation(xg, ops.ACT_ELU)
+    y.backward(g.to(dev))
+    _close(y, ref, 2e-6, "elu")
+    _close(xg.grad, xr.grad, 2e-6, "elu grad")
+
+
 def test_dropout_statistics_and_mask_replay(dev):
     from multipitch_architectures_amd import ops
     ops.manual_seed(123)
