@@ -1440,6 +1440,7 @@ struct Wg15Params {
   int quad;  // 16-byte LDS-DMA staging (aligned geometry): the X window then starts one column further left (ox0-8)
   int co_base;   // first cout of this launch's cout tiles (remainder launch: couts past the last full NBC = 2 tile)
   int dbg;   // diagnostics (env MPA_DEBUG_WG15): 1 = stage only the first tile, 2 = skip the MFMA loop, 3 = 1 + no barriers
+  int fold_R;   // conv_wgrad15f_kernel: the couts [co_base, co_base + fold_R) of this launch, fold_R <= 16 / ceil(15 / NT)
 };
 
 template <int NBC, int CIW>
@@ -1752,11 +1753,176 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad15g_kernel(const Wg15Params 
   }
 }
 
+// Tap-folded variant of conv_wgrad15g_kernel for a remainder of R <= 8 couts (70 = 4 x 16 + 6: DRCNN:L's prefilters;
+// 20 = 16 + 4, 40 = 32 + 8, 100 = 96 + 4; the 6 and 8 couts of the test configurations).  A 16-row MFMA tile with R
+// real cout rows wastes 16 - R of them.  Here the 16 rows are FS = ceil(15 / NT) copies of the R couts (NT = 8: two
+// copies, R <= 8; NT = 4: four copies, R <= 4), copy s reading its dY  s NT rows *above* copy 0's:
+//     acc[(c, s)][t][dx] = sum_{v, px} dY[c][v - s NT][px] * X[v + t - 7][px + dx - 7]  =  dW[c][t + s NT][dx]
+// so NT tap rows of MFMAs per pixel step cover all 15 (NT / 15 of the MFMA work), a tile needs TH + NT - 1 rows of X
+// instead of TH + 14 (taller tiles fit the same LDS), and the price is that the tiles cover OH + (FS - 1) NT "virtual"
+// rows v.  The dY row depends on the lane, so the buffer offset and its bounds test (row in [0, OH), copy < FS) are
+// per-lane VALU work: ~5 instructions per 16-pixel group against 4 NT MFMAs.  Everything else -- X tile by LDS-DMA,
+// dY quads in flight W15G_DEPTH groups ahead, TAIL / EVEN -- is conv_wgrad15g_kernel's.
+template <int NT, bool TAIL, bool EVEN>
+__global__ __launch_bounds__(256, 2) void conv_wgrad15f_kernel(const Wg15Params p) {
+  constexpr int FS = (15 + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* lds_x = lds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kq = lane >> 4, l16 = lane & 15;
+  const int split = blockIdx.x, cig = blockIdx.y;
+  const int ci_first = cig * 4;
+  const int xchp = p.IH * W15_PITCH;
+  const int NtotP = p.Ntot + 1;
+  const bool do_bias = cig == 0 && wave == 0;
+  const int R = p.fold_R;
+  const int fs = l16 / R, fc = l16 - fs * R;     // this lane's A row: cout co_base + fc, copy fs
+  const bool lane_on = fs < FS;
+  float bs = 0.f;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int tilesPerImg = p.tilesY * p.tilesX;
+  const long totalTiles = (long)p.B * tilesPerImg;
+  const int nfull = p.DP >> 4, tail = (p.DP & 15) >> 2;     // nfull >= 1; TAIL == (tail != 0)
+  const float* bfull = lds_x + wave * xchp + 4 * kq + l16 + 1;
+  const float* btail = lds_x + wave * xchp + kq + l16 + 1 + 16 * nfull;
+  const int plane = p.OH * p.OW;
+  const int lane_c = (fc * plane + 4 * kq) * 4, lane_ct = (fc * plane + kq) * 4;     // bytes
+  constexpr int OUTSIDE = 0x7FFFFFF0;      // past num_records: the buffer load returns zero
+
+  for (long tile = split; tile < totalTiles; tile += p.S) {
+    const int b = (int)(tile / tilesPerImg);
+    const int tr = (int)(tile - (long)b * tilesPerImg);
+    const int ty = tr / p.tilesX, tx = tr - ty * p.tilesX;
+    const int oy0 = ty * p.TH, ox0 = tx * p.TW;
+    // one buffer resource per image: the R cout planes of this launch; row and column go into the lane's offset
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dy + ((long)b * p.Cout + p.co_base) * plane), 0,
+                                                        R * plane * 4, 0x00020000);
+    const int row0 = oy0 - fs * NT;      // this lane's dY row at py = 0
+    auto voff = [&](int py, int col, int lc, bool on) {
+      const int row = row0 + py;
+      const bool ok = lane_on && on && (unsigned)row < (unsigned)p.OH;
+      return ok ? lc + (row * p.OW + ox0 + col) * 4 : OUTSIDE;
+    };
+    auto load_full = [&](float4& a, int py, int g) {
+      a = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff(py, 16 * g, lane_c, true), 0, 0));
+    };
+    __syncthreads();
+    glds_stage_x16(lds_x, p.x + (long)b * p.Cin * p.H * p.W, lane, wave, 4, p.IH, W15_PITCH, xchp, p.TX64, ci_first,
+                   oy0 - 7, ox0 - 8, p.Cin, p.H, p.W);
+    float4 an[W15G_DEPTH];       // dY quads of the next W15G_DEPTH groups, in flight
+#pragma unroll
+    for (int d = 0; d < W15G_DEPTH; ++d) load_full(an[d], d / nfull, d % nfull);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    float b0[NT], b1[NT];
+#define W15F_LOAD(Bv, BP, IMM)                                                              \
+  { _Pragma("unroll") for (int t = 0; t < NT; ++t) Bv[t] = (BP)[t * W15_PITCH + (IMM)]; }
+#define W15F_MMA(AV, AC, Bv)                                                                \
+  { _Pragma("unroll") for (int t = 0; t < NT; ++t)                                          \
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.AC, Bv[t], acc[t], 0, 0, 0); }
+    const float* bp = bfull;
+    W15F_LOAD(b0, bp, 0)
+    for (int py = 0; py < p.TH; ++py) {
+      float4 at;
+      if constexpr (TAIL) {     // the row's last 4..12 pixels: k-step s contracts pixels {16 nfull + 4s + kq}
+        at.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff(py, 16 * nfull, lane_ct, true), 0, 0));
+        at.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff(py, 16 * nfull + 4, lane_ct, tail > 1), 0, 0));
+        at.z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff(py, 16 * nfull + 8, lane_ct, tail > 2), 0, 0));
+        at.w = 0.f;
+      }
+      auto group = [&](const int g) {
+        const float4 ac = an[0];
+#pragma unroll
+        for (int d = 0; d + 1 < W15G_DEPTH; ++d) an[d] = an[d + 1];
+        const bool last = g + 1 == nfull;
+        const int npy = last ? py + 1 : py;
+        {
+          int gd = g + W15G_DEPTH, pyd = py;
+          while (gd >= nfull) { gd -= nfull; ++pyd; }
+          if (pyd < p.TH) load_full(an[W15G_DEPTH - 1], pyd, gd);
+        }
+        const float* bpn = last ? (TAIL ? btail + py * W15_PITCH : bfull + npy * W15_PITCH) : bp + 16;
+        if (do_bias) bs += (ac.x + ac.y) + (ac.z + ac.w);
+        W15F_LOAD(b1, bp, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        W15F_MMA(ac, x, b0)
+        __builtin_amdgcn_sched_barrier(0);
+        W15F_LOAD(b0, bp, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        W15F_MMA(ac, y, b1)
+        __builtin_amdgcn_sched_barrier(0);
+        W15F_LOAD(b1, bp, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        W15F_MMA(ac, z, b0)
+        __builtin_amdgcn_sched_barrier(0);
+        W15F_LOAD(b0, bpn, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        W15F_MMA(ac, w, b1)
+        __builtin_amdgcn_sched_barrier(0);
+        bp = bpn;
+      };
+      if constexpr (EVEN) {
+        static_assert(W15G_DEPTH == 2, "the two-groups-per-trip loop renames exactly two in-flight sets");
+        for (int g = 0; g < nfull; g += 2) { group(g); group(g + 1); }
+      } else {
+        for (int g = 0; g < nfull; ++g) group(g);
+      }
+      if constexpr (TAIL) {
+        const float* bpn = bfull + (py + 1) * W15_PITCH;
+        if (do_bias) bs += (at.x + at.y) + at.z;
+        W15F_LOAD(b1, bp, 4)
+        __builtin_amdgcn_sched_barrier(0);
+        W15F_MMA(at, x, b0)
+        __builtin_amdgcn_sched_barrier(0);
+        W15F_LOAD(b0, bp, 8)
+        __builtin_amdgcn_sched_barrier(0);
+        W15F_MMA(at, y, b1)
+        __builtin_amdgcn_sched_barrier(0);
+        W15F_LOAD(b1, bpn, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        W15F_MMA(at, z, b0)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b0[t] = b1[t];
+        bp = bpn;
+      }
+    }
+#undef W15F_LOAD
+#undef W15F_MMA
+  }
+  // D[row = (copy, cout) (kq*4+r)][col = dx (l16)]
+  float* out = p.ws + (long)split * p.Cout * NtotP;
+  const int ci = ci_first + wave;
+  if (l16 < 15 && ci < p.Cin) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = kq * 4 + r, s = m / R, c = m - s * R;
+      if (s >= FS) continue;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int tap = t + s * NT;
+        if (tap < 15) out[(long)(p.co_base + c) * NtotP + ci * 225 + tap * 15 + l16] = acc[t][r];
+      }
+    }
+  }
+  if (do_bias) {       // copy 0 (lanes l16 < R) saw every dY row exactly once
+    float v = bs;
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (kq == 0 && l16 < R) out[(long)(p.co_base + l16) * NtotP + p.Ntot] = v;
+  }
+}
+
 struct Wg15Plan {
   int NBC, CIW, COT, coTiles, ciGroups, TH, TW, DP, tilesY, tilesX, IH, IW, DCP, S, TX64, TD64, quad;
   int ga;    // conv_wgrad15g_kernel: dY operand from global memory, LDS holds the X tile only
-  int rem_split;   // the last, at most half-filled 32-cout tile runs as a second launch with 16-cout tiles
-  size_t lds_bytes;
+  // dY-from-global launches: couts [0, 32 n32) in 32-cout tiles, then an optional 16-cout tile, then an optional
+  // tap-folded remainder of fold_R <= 8 couts (conv_wgrad15f_kernel) with its own row tiling
+  int n32, has16, fold_R, fold_NT, fTH, ftilesY, fIH, fTX64;
+  size_t lds_bytes, flds_bytes;
   bool ok;
 };
 
@@ -1823,12 +1989,38 @@ Wg15Plan plan_wgrad15(const mpa_conv_desc* d) {
   if (!pl.ok) return pl;
   const long totalTiles = (long)d->B * pl.tilesY * pl.tilesX;
   const long per_cu = std::max<long>(1, std::min<long>(2, (160 * 1024) / (long)pl.lds_bytes));
-  // Couts that fill the last 32-cout tile by at most half (70 = 2 x 32 + 6: DRCNN:L's prefilters) go to a second
-  // launch with 16-cout tiles: 80 instead of 96 cout rows of MFMA work (-17 % on those layers).  Both launches share
-  // S (the workspace slices), chosen so that the main launch is a whole number of rounds.
-  const int rem = d->Cout % 32;
-  pl.rem_split = (pl.ga && pl.NBC == 2 && rem > 0 && rem <= 16 && pl.coTiles > 1) ? 1 : 0;
-  const long slots = 256 * per_cu, groups = (long)pl.ciGroups * (pl.coTiles - pl.rem_split);
+  // Couts split over up to three launches that share S (the workspace slices): full 32-cout tiles; a 16-cout tile when
+  // 9..24 couts are left (16 instead of 32 rows of MFMA work for a half-filled tile); and whatever is then left, at
+  // most 8 couts, tap-folded (70 = 2 x 32 + fold 6 for DRCNN:L's prefilters, 20 = 16 + fold 4, 40 = 32 + fold 8).
+  pl.n32 = pl.coTiles; pl.has16 = 0; pl.fold_R = 0;
+  if (pl.ga && !getenv("MPA_WG15_NOFOLD")) {
+    pl.n32 = d->Cout / 32;
+    int rem = d->Cout - 32 * pl.n32;
+    if (rem > 24) { pl.n32 += 1; rem = 0; }
+    if (rem > 8) { pl.has16 = 1; rem = rem > 16 ? rem - 16 : 0; }
+    pl.fold_R = rem;
+  } else if (pl.ga) {      // the previous rule: a last 32-cout tile filled by at most half runs as a 16-cout tile
+    const int rem = d->Cout % 32;
+    if (pl.NBC == 2 && rem > 0 && rem <= 16 && pl.coTiles > 1) { pl.n32 = pl.coTiles - 1; pl.has16 = 1; }
+    else if (pl.NBC == 1) { pl.n32 = 0; pl.has16 = 1; }
+  }
+  if (pl.fold_R) {
+    // the fold's row tiling: OH + (FS - 1) NT virtual rows, IH = TH + NT - 1 rows of X per tile
+    pl.fold_NT = pl.fold_R <= 4 ? 4 : 8;
+    const int FS = (15 + pl.fold_NT - 1) / pl.fold_NT, OHv = OH + (FS - 1) * pl.fold_NT;
+    double best = 1e300;
+    for (int TH = std::min(OHv, 64); TH >= 1; --TH) {
+      const int IH = TH + pl.fold_NT - 1;
+      const long tx64 = (long)4 * IH * W15_PITCH;
+      if (tx64 * 4 > budget) continue;
+      const int ty = (int)mpa_cdiv(OHv, TH);
+      const double mfma = (double)TH * (pl.TW / 4) * pl.fold_NT * 32.0;
+      const double stage = (double)tx64 / 64.0 * 80.0 / 4.0;
+      const double cost = (double)ty * (mfma + stage + 3000.0);
+      if (cost < best) { best = cost; pl.fTH = TH; pl.ftilesY = ty; pl.fIH = IH; pl.fTX64 = (int)tx64; pl.flds_bytes = (size_t)tx64 * 4; }
+    }
+  }
+  const long slots = 256 * per_cu, groups = (long)pl.ciGroups * std::max(1, pl.n32);
   long S = std::max<long>(1, (2 * slots) / groups);
   if (S > totalTiles) S = totalTiles;
   if (S > 1024) S = 1024;
@@ -1993,8 +2185,11 @@ int mpa_conv2d_describe_plan(const mpa_conv_desc* d, int mode, char* buf, int bu
   if (mode == 2) {
     Wg15Plan q = plan_wgrad15(d);
     if (q.ok) {
-      snprintf(buf, buflen, "wgrad15%s<%d,%d> COT=%d coTiles=%d ciGroups=%d tile=%dx%d (DP %d) tiles=%dx%d S=%d lds=%zuB",
-               q.ga ? "g" : "", q.NBC, q.CIW, q.COT, q.coTiles, q.ciGroups, q.TH, q.TW, q.DP, q.tilesY, q.tilesX, q.S, q.lds_bytes);
+      int n = snprintf(buf, buflen, "wgrad15%s<%d,%d> COT=%d coTiles=%d ciGroups=%d tile=%dx%d (DP %d) tiles=%dx%d S=%d lds=%zuB",
+                       q.ga ? "g" : "", q.NBC, q.CIW, q.COT, q.coTiles, q.ciGroups, q.TH, q.TW, q.DP, q.tilesY, q.tilesX, q.S, q.lds_bytes);
+      if (q.ga && n > 0 && n < buflen)
+        snprintf(buf + n, buflen - n, " launches: %dx32 %s fold=%d (NT %d, tile rows %d x %d)", q.n32, q.has16 ? "+16" : "",
+                 q.fold_R, q.fold_NT, q.fTH, q.ftilesY);
       return MPA_OK;
     }
     WgPlan w = plan_wgrad(d);
@@ -2055,27 +2250,38 @@ int mpa_conv2d_bwd_weight(const mpa_conv_desc* d, const float* x, const float* d
         MPA_WG15G_ATTR(1, false); MPA_WG15G_ATTR(2, false); MPA_WG15G_ATTR(1, true); MPA_WG15G_ATTR(2, true);
         MPA_WG15G_ATTR(1, false, true); MPA_WG15G_ATTR(2, false, true); MPA_WG15G_ATTR(1, true, true); MPA_WG15G_ATTR(2, true, true);
 #undef MPA_WG15G_ATTR
+#define MPA_WG15F_ATTR(...) (void)hipFuncSetAttribute((const void*)conv_wgrad15f_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)
+        MPA_WG15F_ATTR(8, false, false); MPA_WG15F_ATTR(8, false, true); MPA_WG15F_ATTR(8, true, false); MPA_WG15F_ATTR(8, true, true);
+        MPA_WG15F_ATTR(4, false, false); MPA_WG15F_ATTR(4, false, true); MPA_WG15F_ATTR(4, true, false); MPA_WG15F_ATTR(4, true, true);
+#undef MPA_WG15F_ATTR
         attr_g = true;
       }
       const bool tl = (p15.DP & 15) != 0;
       const bool ev = ((p15.DP >> 4) & 1) == 0;
-      // (remainder launch: see plan_wgrad15)
-      const bool split_rem = p15.rem_split != 0;
 #define MPA_WG15G_GO(...) MPA_LAUNCH((conv_wgrad15g_kernel<__VA_ARGS__>), grid15, dim3(256), p15.lds_bytes, s15, q)
-      for (int part = 0; part < (split_rem ? 2 : 1); ++part) {
-        int nbc = p15.NBC;
-        if (split_rem) {
-          if (part == 0) { grid15.z = (unsigned)(p15.coTiles - 1); q.co_base = 0; q.COT = 32; }
-          else { grid15.z = 1; q.co_base = (p15.coTiles - 1) * 32; q.COT = 16; nbc = 1; }
-        }
-        if (nbc == 1) {
-          if (tl) { if (ev) MPA_WG15G_GO(1, true, true); else MPA_WG15G_GO(1, true, false); }
-          else { if (ev) MPA_WG15G_GO(1, false, true); else MPA_WG15G_GO(1, false, false); }
+#define MPA_WG15F_GO(...) MPA_LAUNCH((conv_wgrad15f_kernel<__VA_ARGS__>), grid15, dim3(256), p15.flds_bytes, s15, q)
+      if (p15.n32) {
+        grid15.z = (unsigned)p15.n32; q.co_base = 0; q.COT = 32;
+        if (tl) { if (ev) MPA_WG15G_GO(2, true, true); else MPA_WG15G_GO(2, true, false); }
+        else { if (ev) MPA_WG15G_GO(2, false, true); else MPA_WG15G_GO(2, false, false); }
+      }
+      if (p15.has16) {
+        grid15.z = 1; q.co_base = 32 * p15.n32; q.COT = 16;
+        if (tl) { if (ev) MPA_WG15G_GO(1, true, true); else MPA_WG15G_GO(1, true, false); }
+        else { if (ev) MPA_WG15G_GO(1, false, true); else MPA_WG15G_GO(1, false, false); }
+      }
+      if (p15.fold_R) {
+        grid15.z = 1; q.co_base = 32 * p15.n32 + 16 * p15.has16; q.COT = 16; q.fold_R = p15.fold_R;
+        q.TH = p15.fTH; q.tilesY = p15.ftilesY; q.IH = p15.fIH; q.TX64 = p15.fTX64;
+        if (p15.fold_NT == 8) {
+          if (tl) { if (ev) MPA_WG15F_GO(8, true, true); else MPA_WG15F_GO(8, true, false); }
+          else { if (ev) MPA_WG15F_GO(8, false, true); else MPA_WG15F_GO(8, false, false); }
         } else {
-          if (tl) { if (ev) MPA_WG15G_GO(2, true, true); else MPA_WG15G_GO(2, true, false); }
-          else { if (ev) MPA_WG15G_GO(2, false, true); else MPA_WG15G_GO(2, false, false); }
+          if (tl) { if (ev) MPA_WG15F_GO(4, true, true); else MPA_WG15F_GO(4, true, false); }
+          else { if (ev) MPA_WG15F_GO(4, false, true); else MPA_WG15F_GO(4, false, false); }
         }
       }
+#undef MPA_WG15F_GO
 #undef MPA_WG15G_GO
     } else
     if (p15.NBC == 1) MPA_LAUNCH((conv_wgrad15_kernel<1, 1>), grid15, dim3(256), p15.lds_bytes, s15, q);

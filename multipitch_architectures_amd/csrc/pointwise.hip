@@ -76,6 +76,145 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
   }
 }
 
+// The CNN families' prefilter tail -- MaxPool2d((3,1), stride 1, padding (1,0)) -> Dropout [-> + residual]
+// (basic_cnns.py:374-377 and the residual add of deep_cnn_segm_sigmoid.forward, :414-418) -- as one pass over the
+// activations instead of three (pool with an int32 argmax plane, dropout, add: 2.6 GB of traffic per 290 MB tensor,
+// against 0.94 GB here).  A thread owns V adjacent columns and R consecutive rows: it loads the R + 2 input rows once
+// and forms the R windows in registers.  Same rules as the separate kernels, bit for bit: first maximum wins and a NaN
+// propagates (maxpool_fwd_plane_kernel), the keep mask is rng_uniform(seed, base + offset + flat index) >= p
+// (dropout_kernel), and the sum is (pooled * scale) + residual.  `which` records the window row (0..2) of the maximum.
+template <int R, int V>
+__global__ __launch_bounds__(256) void pool3_drop_add_fwd_kernel(const float* __restrict__ h, const float* __restrict__ res,
+                                                                 float* __restrict__ out, int8_t* __restrict__ which,
+                                                                 long planes, int H, int W, float p, float scale,
+                                                                 const uint64_t* __restrict__ rng_state, uint64_t local) {
+  const int WV = W / V, nblk = (H + R - 1) / R;
+  const long items = planes * nblk * WV;
+  const bool drop = p > 0.f;
+  const uint64_t seed = drop ? rng_state[0] : 0, offset = drop ? rng_state[1] + local : 0;
+  for (long item = (long)blockIdx.x * 256 + threadIdx.x; item < items; item += (long)gridDim.x * 256) {
+    const long pb = item / WV;
+    const int col = (int)(item - pb * WV) * V;
+    const long pl = pb / nblk;
+    const int r0 = (int)(pb - pl * nblk) * R;
+    const long base = pl * H * W + col;
+    float v[R + 2][V];
+#pragma unroll
+    for (int j = 0; j < R + 2; ++j) {
+      const int row = r0 - 1 + j;
+      if (row >= 0 && row < H) {
+        if constexpr (V == 4) {
+          const float4 t = *reinterpret_cast<const float4*>(h + base + (long)row * W);
+          v[j][0] = t.x; v[j][1] = t.y; v[j][2] = t.z; v[j][3] = t.w;
+        } else {
+#pragma unroll
+          for (int c = 0; c < V; ++c) v[j][c] = h[base + (long)row * W + c];
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < V; ++c) v[j][c] = 0.f;      // never looked at
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = r0 + r;
+      if (row >= H) break;
+      const long e = base + (long)row * W;
+      float o[V];
+      int8_t wsel[V];
+#pragma unroll
+      for (int c = 0; c < V; ++c) {
+        float best = 0.f;
+        int sel = -1;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const int iy = row - 1 + d;
+          if (iy < 0 || iy >= H) continue;
+          const float t = v[r + d][c];
+          if (sel < 0 || t > best || t != t) { best = t; sel = d; }
+        }
+        float y = best;
+        if (drop) y = rng_uniform(seed, offset + (uint64_t)(e + c)) >= p ? best * scale : 0.f;
+        o[c] = res ? y + res[e + c] : y;
+        wsel[c] = (int8_t)sel;
+      }
+      if constexpr (V == 4) {
+        *reinterpret_cast<float4*>(out + e) = float4{o[0], o[1], o[2], o[3]};
+        if (which) *reinterpret_cast<char4*>(which + e) = char4{wsel[0], wsel[1], wsel[2], wsel[3]};
+      } else {
+#pragma unroll
+        for (int c = 0; c < V; ++c) { out[e + c] = o[c]; if (which) which[e + c] = wsel[c]; }
+      }
+    }
+  }
+}
+
+// Backward of the pool + dropout part (the residual's gradient is dout itself): gather form, fixed order -- input row
+// rho collects g(r) = keep(r) * scale * dout(r) from the windows r = rho + 1, rho, rho - 1 whose recorded row is rho.
+template <int R, int V>
+__global__ __launch_bounds__(256) void pool3_drop_bwd_kernel(const float* __restrict__ dout, const int8_t* __restrict__ which,
+                                                             float* __restrict__ dh, long planes, int H, int W, float p,
+                                                             float scale, const uint64_t* __restrict__ rng_state,
+                                                             uint64_t local) {
+  const int WV = W / V, nblk = (H + R - 1) / R;
+  const long items = planes * nblk * WV;
+  const bool drop = p > 0.f;
+  const uint64_t seed = drop ? rng_state[0] : 0, offset = drop ? rng_state[1] + local : 0;
+  for (long item = (long)blockIdx.x * 256 + threadIdx.x; item < items; item += (long)gridDim.x * 256) {
+    const long pb = item / WV;
+    const int col = (int)(item - pb * WV) * V;
+    const long pl = pb / nblk;
+    const int r0 = (int)(pb - pl * nblk) * R;
+    const long base = pl * H * W + col;
+    float g[R + 2][V];
+    int8_t w[R + 2][V];
+#pragma unroll
+    for (int j = 0; j < R + 2; ++j) {
+      const int row = r0 - 1 + j;
+      if (row >= 0 && row < H) {
+        const long e = base + (long)row * W;
+        if constexpr (V == 4) {
+          const float4 t = *reinterpret_cast<const float4*>(dout + e);
+          const char4 s = *reinterpret_cast<const char4*>(which + e);
+          g[j][0] = t.x; g[j][1] = t.y; g[j][2] = t.z; g[j][3] = t.w;
+          w[j][0] = s.x; w[j][1] = s.y; w[j][2] = s.z; w[j][3] = s.w;
+        } else {
+#pragma unroll
+          for (int c = 0; c < V; ++c) { g[j][c] = dout[e + c]; w[j][c] = which[e + c]; }
+        }
+        if (drop) {
+#pragma unroll
+          for (int c = 0; c < V; ++c) g[j][c] = rng_uniform(seed, offset + (uint64_t)(e + c)) >= p ? g[j][c] * scale : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < V; ++c) { g[j][c] = 0.f; w[j][c] = -1; }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = r0 + r;
+      if (row >= H) break;
+      float o[V];
+#pragma unroll
+      for (int c = 0; c < V; ++c) {
+        // window r = rho + 1 holds rho as its row 0, window rho as its row 1, window rho - 1 as its row 2
+        float a = 0.f;
+        if (w[r + 2][c] == 0) a += g[r + 2][c];
+        if (w[r + 1][c] == 1) a += g[r + 1][c];
+        if (w[r][c] == 2) a += g[r][c];
+        o[c] = a;
+      }
+      const long e = base + (long)row * W;
+      if constexpr (V == 4) *reinterpret_cast<float4*>(dh + e) = float4{o[0], o[1], o[2], o[3]};
+      else {
+#pragma unroll
+        for (int c = 0; c < V; ++c) dh[e + c] = o[c];
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                   float* __restrict__ y, long n) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = a[i] + b[i];
@@ -368,6 +507,39 @@ int mpa_dropout(const float* x, float* y, int64_t n, float p, const uint64_t* rn
   if (n == 0) return MPA_OK;
   MPA_LAUNCH(dropout_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, (long)n, p, 1.f / (1.f - p),
                      rng_state, offset);
+  return mpa_launch_status();
+}
+int mpa_pool3_dropout_add_fwd(const float* h, const float* residual, float* out, int8_t* which, int64_t planes, int H, int W,
+                              float p, const uint64_t* rng_state, uint64_t offset, void* stream) {
+  if (!h || !out || planes < 0 || H <= 0 || W <= 0 || p < 0.f || p >= 1.f || (p > 0.f && !rng_state)) return MPA_ERR_ARG;
+  if (planes == 0) return MPA_OK;
+  const float scale = 1.f / (1.f - p);
+  constexpr int R = 15;
+  const bool quad = W % 4 == 0 && (((uintptr_t)h | (uintptr_t)out | (uintptr_t)residual | (uintptr_t)which) & 15) == 0;
+  const long items = planes * mpa_cdiv(H, R) * (quad ? W / 4 : W);
+  if (quad)
+    MPA_LAUNCH((pool3_drop_add_fwd_kernel<R, 4>), dim3(blocks_for(items)), dim3(256), 0, (hipStream_t)stream, h, residual, out,
+               which, (long)planes, H, W, p, scale, rng_state, offset);
+  else
+    MPA_LAUNCH((pool3_drop_add_fwd_kernel<R, 1>), dim3(blocks_for(items)), dim3(256), 0, (hipStream_t)stream, h, residual, out,
+               which, (long)planes, H, W, p, scale, rng_state, offset);
+  return mpa_launch_status();
+}
+int mpa_pool3_dropout_bwd(const float* dout, const int8_t* which, float* dh, int64_t planes, int H, int W, float p,
+                          const uint64_t* rng_state, uint64_t offset, void* stream) {
+  if (!dout || !which || !dh || planes < 0 || H <= 0 || W <= 0 || p < 0.f || p >= 1.f || (p > 0.f && !rng_state))
+    return MPA_ERR_ARG;
+  if (planes == 0) return MPA_OK;
+  const float scale = 1.f / (1.f - p);
+  constexpr int R = 15;
+  const bool quad = W % 4 == 0 && (((uintptr_t)dout | (uintptr_t)dh | (uintptr_t)which) & 15) == 0;
+  const long items = planes * mpa_cdiv(H, R) * (quad ? W / 4 : W);
+  if (quad)
+    MPA_LAUNCH((pool3_drop_bwd_kernel<R, 4>), dim3(blocks_for(items)), dim3(256), 0, (hipStream_t)stream, dout, which, dh,
+               (long)planes, H, W, p, scale, rng_state, offset);
+  else
+    MPA_LAUNCH((pool3_drop_bwd_kernel<R, 1>), dim3(blocks_for(items)), dim3(256), 0, (hipStream_t)stream, dout, which, dh,
+               (long)planes, H, W, p, scale, rng_state, offset);
   return mpa_launch_status();
 }
 int mpa_store_ptrs(const void** table, const void* const* host_ptrs, int n, void* stream) {

@@ -81,8 +81,10 @@ class deep_cnn_segm_sigmoid(nn.Module):
         for p in range(0, self.n_prefilt_layers - 1):
             prefilt_layer = self.prefilt_list[p]
             if self.residual:
-                x_new = prefilt_layer(x)
-                x = ops.add(x_new, x)
+                if prefilt_layer._forward_hooks or prefilt_layer._forward_pre_hooks:
+                    x = ops.add(prefilt_layer(x), x)             # a hooked stage returns x_new, as the reference's does
+                else:
+                    x = prefilt_layer.forward(x, residual=x)     # x_new + x: the add is part of the stage's last kernel
             else:
                 x = prefilt_layer(x)
         conv2_lrelu = self.conv2(x)

@@ -214,13 +214,18 @@ class ConvActPoolDrop(nn.Sequential):
     basic_cnns.py:371-401, unet_cnns.py:538-549) run as conv+bias+LeakyReLU fused in the conv epilogue, then pool,
     then dropout."""
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
         mods = list(self)
         conv, act = mods[0], mods[1]
         h = conv(x, act.act, act.slope)
-        for m in mods[2:]:
+        rest = mods[2:]
+        if (len(rest) == 2 and isinstance(rest[0], MaxPool2d) and isinstance(rest[1], Dropout)
+                and (rest[0].kernel_size, rest[0].stride, rest[0].padding) == ((3, 1), (1, 1), (1, 0))):
+            # the prefilter tail (pool over 3 frames, dropout, residual add) is one kernel
+            return ops.pool3_dropout_add(h, residual, rest[1].p, self.training)
+        for m in rest:
             h = m(h)
-        return h
+        return h if residual is None else ops.add(h, residual)
 
 
 class OutputHead(nn.Sequential):

@@ -246,3 +246,20 @@ def test_state_dict_roundtrip_and_old_key_layout(dev):
     old = double_conv(4, 8, convdrop=None)
     assert [k for k in old.state_dict() if k.endswith("weight")] == [
         "double_conv.0.weight", "double_conv.1.weight", "double_conv.3.weight", "double_conv.4.weight"]
+
+
+def test_hooked_residual_stage_returns_x_new_and_the_model_output_is_unchanged(dev):
+    """DRCNN: the residual add is fused into the prefilter stage's last kernel unless the stage carries a hook; a hook
+    must see x_new (what the reference's nn.Sequential returns, basic_cnns.py:414-418) and the output must not move"""
+    model = build_model("tiny:DRCNN", dev).eval()
+    x, _ = synth_batch(2, 75)
+    with torch.no_grad():
+        y0 = model(x.to(dev))
+        seen = {}
+        h = model.prefilt_list[0].register_forward_hook(lambda m, i, o: seen.setdefault("o", o))
+        y1 = model(x.to(dev))
+        h.remove()
+        x_in = model.conv1(model.layernorm.forward_cf(x.to(dev)))
+        x_new = model.prefilt_list[0](x_in)
+    assert torch.equal(y0, y1)
+    assert torch.equal(seen["o"], x_new)

@@ -626,6 +626,41 @@ def test_conv_backward_weight_every_global_dy_kernel(dev, variant, geom, monkeyp
     _close(db, gy.double().sum((0, 2, 3)), 5e-5, "db")
 
 
+@pytest.mark.parametrize("W", [16, 20, 24, 28, 32, 44, 216], ids=lambda w: f"w{w}")
+@pytest.mark.parametrize("Cout,expect", [(3, "0x32  fold=3 (NT 4"), (4, "0x32  fold=4 (NT 4"), (6, "0x32  fold=6 (NT 8"),
+                                         (8, "0x32  fold=8 (NT 8"), (20, "0x32 +16 fold=4"), (38, "1x32  fold=6"),
+                                         (56, "1x32 +16 fold=8"), (58, "2x32  fold=0")], ids=lambda v: str(v))
+def test_conv_backward_weight_15x15_cout_remainders(dev, W, Cout, expect):
+    """15x15 weight gradient: couts left over after the 32- and 16-cout tiles (at most 8) go through the tap-folded kernel
+    (the 16 MFMA rows are 2 or 4 row-shifted copies of the remainder).  Every (NT, tail, even) instantiation, tile rows
+    both shorter and taller than the shift, and every launch combination against torch in float64."""
+    import ctypes
+    from multipitch_architectures_amd import _lib as L
+    B, Cin = 3, 5
+    H = 75 if W == 216 else (5 if W == 44 else 19)
+    if W == 216 and Cout not in (6, 20):
+        pytest.skip("full-size rows for two remainders only")
+    d = L.ConvDesc(B, Cin, H, W, Cout, 15, 15, 1, 1, 7, 7)
+    buf = ctypes.create_string_buffer(512)
+    lib = L.load()
+    assert lib.mpa_conv2d_describe_plan(ctypes.byref(d), 2, buf, 512) == 0
+    plan = buf.value.decode()
+    assert plan.startswith("wgrad15g<") and ("launches: " + expect) in plan, plan
+    x = _rand((B, Cin, H, W), 51)
+    gy = _rand((B, Cout, H, W), 52)
+    ref_w = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 15, 15), gy.double(), stride=(1, 1), padding=(7, 7))
+    dw = torch.full((Cout, Cin, 15, 15), float("nan"), device=dev)
+    db = torch.full((Cout,), float("nan"), device=dev)
+    n = lib.mpa_conv2d_bwd_weight_workspace(ctypes.byref(d))
+    ws = torch.full((n // 4,), float("nan"), device=dev)
+    xg, gyg = x.to(dev), gy.to(dev)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.mpa_conv2d_bwd_weight(ctypes.byref(d), P(xg), P(gyg), P(dw), P(db), P(ws), n, st) == 0
+    _close(dw, ref_w, 5e-5, "dw")
+    _close(db, gy.double().sum((0, 2, 3)), 5e-5, "db")
+
+
 def test_maxpool_head_window_nan_and_ties(dev):
     """the head's (13,1) column kernel has a fast path for interior blocks without NaNs: NaNs must still propagate like
     torch's, and ties must still pick the first maximum"""
@@ -643,3 +678,59 @@ def test_maxpool_head_window_nan_and_ties(dev):
     b = xr.to(dev).requires_grad_(True)
     ops.max_pool2d(b, (13, 1), (1, 1), (6, 0)).sum().backward()
     assert torch.equal(b.grad.cpu(), a.grad)
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 75, 216), (3, 4, 7, 10), (1, 2, 1, 8), (2, 3, 31, 13), (1, 1, 2, 4)],
+                         ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("p", [0.2, 0.0])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_pool3_dropout_add_matches_the_three_separate_ops(dev, shape, p, with_res):
+    """the fused prefilter tail (MaxPool2d((3,1),1,(1,0)) -> Dropout -> + residual, basic_cnns.py:374-377,414-418) against
+    max_pool2d + dropout + add: same mask (same position in the dropout stream), outputs bit for bit, gradients to
+    rounding (the separate pool backward adds overlapping windows in no fixed order)"""
+    from multipitch_architectures_amd import ops
+    h = _rand(shape, 61)
+    h[0, 0, 0, :3] = h[0, 0, min(1, shape[2] - 1), :3]        # ties: the first maximum must win
+    res = _rand(shape, 62) if with_res else None
+    gy = _rand(shape, 63).to(dev)
+
+    def run(fused):
+        ops.manual_seed(1234)
+        hg = h.to(dev).requires_grad_(True)
+        rg = res.to(dev).requires_grad_(True) if with_res else None
+        pre = ops.dropout(_rand((7,), 1).to(dev), 0.5, True)      # the tail does not start at stream position 0
+        if fused:
+            y = ops.pool3_dropout_add(hg, rg, p, True)
+        else:
+            y = ops.dropout(ops.max_pool2d(hg, (3, 1), (1, 1), (1, 0)), p, True)
+            if with_res:
+                y = ops.add(y, rg)
+        post = ops.dropout(torch.ones(64, device=dev), 0.5, True)  # ... and leaves it where the separate ops do
+        y.backward(gy)
+        ops.rng_advance()
+        return y.detach(), hg.grad, (rg.grad if with_res else None), pre.detach(), post.detach()
+
+    yf, dhf, drf, pre_f, post_f = run(True)
+    yu, dhu, dru, pre_u, post_u = run(False)
+    assert torch.equal(yf, yu)
+    assert torch.equal(pre_f, pre_u) and torch.equal(post_f, post_u)
+    _close(dhf, dhu, 1e-6, "dh")
+    if with_res:
+        assert torch.equal(drf, dru)
+    # and against torch (pool + the mask recovered from the op itself)
+    ref = F.max_pool2d(h.double(), (3, 1), (1, 1), (1, 0))
+    if p == 0.0:
+        _close(yf, ref + (res.double() if with_res else 0), 1e-6, "y vs torch")
+
+
+def test_pool3_dropout_add_nan_propagates_and_eval_mode(dev):
+    from multipitch_architectures_amd import ops
+    h = _rand((1, 2, 9, 8), 5)
+    h[0, 1, 4, 3] = float("nan")
+    y = ops.pool3_dropout_add(h.to(dev), None, 0.2, False)           # eval: no mask
+    ref = F.max_pool2d(h, (3, 1), (1, 1), (1, 0))
+    assert torch.equal(torch.isnan(y.cpu()), torch.isnan(ref))
+    ok = ~torch.isnan(ref)
+    assert torch.equal(y.cpu()[ok], ref[ok])
+    with pytest.raises(RuntimeError):
+        ops.pool3_dropout_add(h.to(dev), _rand((1, 2, 9, 4), 6).to(dev), 0.2, True)
