@@ -32,6 +32,9 @@ def parse_args(argv=None):
                     "probes after the timed region (profiling runs)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying "
                     "the captured HIP graph of the step")
+    ap.add_argument("--dp-rehearsal", action="store_true", help="with --gpus 1: run what a data-parallel rank runs (RCCL "
+                    "process group of one rank, gradient hooks, bucketed asynchronous all-reduces, kernel-by-kernel "
+                    "step) -- the per-rank cost of the data-parallel machinery on a one-GPU box; not a BASELINE line")
     return ap.parse_args(argv)
 
 
@@ -257,8 +260,16 @@ def main():
         raise SystemExit(f"rank {rank}: LOCAL_RANK={local_rank} but only {ndev} GPUs are visible")
     torch.cuda.set_device(local_rank % ndev)
     dev = torch.device("cuda", local_rank % ndev)
-    if world > 1:
+    dp = world > 1 or args.dp_rehearsal          # process group + gradient averager
+    if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -270,13 +281,13 @@ def main():
         args.global_batch = baseline_batch.get(args.config, 256)
     torch.manual_seed(0)                                    # PyTorch default init, seed 0 (timing is value independent)
     model = getattr(nn_models, cfg["cls"])(**cfg["kwargs"]).to(dev).train()
-    if world > 1:
+    if dp:
         for p in model.parameters():
             dist.broadcast(p.data, 0)
     is_punet = cfg["cls"].endswith("polyphony_classif_softmax")
     loss_fn = PolyphonyLoss() if is_punet else BCELoss()
     opt = AdamW(model.parameters(), lr=cfg["lr"], betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
-    averager = GradientAverager(model.parameters()) if world > 1 else None
+    averager = GradientAverager(model.parameters()) if dp else None
 
     lo, hi = shard_range(args.global_batch, rank, world)
     x, y = synth_batch(args.global_batch, args.frames, seed=1234)
@@ -375,8 +386,8 @@ def main():
             "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic", "patches_per_s": patches_per_s, "loss": float(loss.detach()),
-            "ranks_seen": dist.get_world_size() if world > 1 else 1, "devices": devices,
-            "dist_backend": backend if world > 1 else None,
+            "ranks_seen": dist.get_world_size() if dp else 1, "devices": devices,
+            "dist_backend": backend if dp else None, "dp_rehearsal": bool(args.dp_rehearsal and world == 1),
             "config": {"workload": f"{args.config} ({cfg['cls']}) train step fwd+bwd+AdamW, global batch "
                                    f"{args.global_batch}, patches (6,{args.frames},216) -> ({args.frames - 74},72), "
                                    + (f"BASELINE.json configs[{[c for c, _ in BASELINE_CONFIGS].index(args.config)}]"
@@ -404,7 +415,7 @@ def main():
             out["eval_measures"] = eval_measures_probe(not args.no_cpu_baseline)
             out["segment_inference"] = segment_inference_probe(model)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dp:
         dist.destroy_process_group()
 
 

@@ -66,3 +66,16 @@ def test_two_rank_train_steps_keep_parameters_identical(backend):
     for r in res:
         assert r["params_identical"] and r["finite"], r
         assert all(0 < v < 10 for v in r["losses"])
+
+
+@pytest.mark.parametrize("case", ["grads", "step"])
+def test_single_rank_rccl_communicator_runs_the_same_path(case):
+    """what a one-GPU box can run of RCCL itself: a world of one rank -- `init_process_group("nccl", device_id=...)`, the
+    communicator, the bucketed asynchronous all-reduces on RCCL's stream and their hand-over to the compute stream are
+    the real thing, only the ring is trivial"""
+    (r,) = _run("nccl", case, world=1)
+    assert r["world"] == 1
+    if case == "grads":
+        assert r["buckets"] > 1 and r["rel_err"] < 2e-5, r
+    else:
+        assert r["params_identical"] and r["finite"] and all(0 < v < 10 for v in r["losses"]), r
