@@ -1453,9 +1453,9 @@ __global__ __launch_bounds__(256) void conv_wgrad15_kernel(const Wg15Params p) {
   const int split = blockIdx.x, cig = blockIdx.y, cot = blockIdx.z;
   const int ci_first = cig * 4 * CIW;
   const int xchp = p.IH * W15_PITCH;
-  // Two workgroups share a CU and start in lock-step, so they would stage (and idle the MFMA pipe) together forever.
-  // The one whose LDS allocation does not start at 0 gets issue priority: it runs at full speed, the other fills the
-  // gaps and the first one's staging time -- and each one's staging now falls into the other's compute phase.
+  // (Two workgroups share a CU and start in lock-step.  Giving the one whose LDS allocation does not start at 0 issue
+  // priority, so that each one's staging falls into the other's compute phase, was measured in round 1 and changed
+  // nothing: the LDS-DMA issue cost is paid by the CU whatever the phase between the two -- see conv_wgrad15g_kernel.)
   const int NtotP = p.Ntot + 1;
   const bool do_bias = cig == 0;
   float bsum = 0.f;
