@@ -297,6 +297,138 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const float* __restrict_
   }
 }
 
+// 16-byte variant (Ws % 4 == 0), one flat index space over the whole tensor: a thread owns four adjacent outputs of
+// one row.  (Measured against the plane-per-workgroup form below for the 216-wide level at batch 256: 257 vs 369 us --
+// 0.86 GB; the wave-per-row kernel took 333 us.)  Same arithmetic per element as upcat_fwd_kernel.
+__global__ __launch_bounds__(256) void upcat_fwd4_kernel(const float* __restrict__ x1, const float* __restrict__ skip,
+                                                         float* __restrict__ out, int B, int C1, int H1, int W1, int Cs,
+                                                         int Hs, int Ws) {
+  const int Ct = Cs + C1, WQ = Ws >> 2;
+  const long total = (long)B * Ct * Hs * WQ;
+  const int UH = 2 * H1, UW = 2 * W1;
+  const int padT = (Hs - UH) / 2, padL = (Ws - UW) / 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / WQ;
+    const int x = (int)(i - r * WQ) * 4;
+    const long bc = r / Hs;
+    const int y = (int)(r - bc * Hs);
+    const int b = (int)(bc / Ct);
+    const int c = (int)(bc - (long)b * Ct);
+    float4 v = float4{0.f, 0.f, 0.f, 0.f};
+    if (c < Cs) {
+      v = *reinterpret_cast<const float4*>(skip + (((long)b * Cs + c) * Hs + y) * Ws + x);
+    } else {
+      const int uy = y - padT;
+      if (uy >= 0 && uy < UH) {
+        int y0, y1;
+        float ly;
+        bilin_src(uy, H1, UH, y0, y1, ly);
+        const float hy = 1.f - ly;
+        const float* p0 = x1 + (((long)b * C1 + (c - Cs)) * H1 + y0) * W1;
+        const float* p1 = x1 + (((long)b * C1 + (c - Cs)) * H1 + y1) * W1;
+        float o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int ux = x + u - padL;
+          o[u] = 0.f;
+          if (ux >= 0 && ux < UW) {
+            int x0, x1i;
+            float lx;
+            bilin_src(ux, W1, UW, x0, x1i, lx);
+            const float hx = 1.f - lx;
+            o[u] = hy * (hx * p0[x0] + lx * p0[x1i]) + ly * (hx * p1[x0] + lx * p1[x1i]);
+          }
+        }
+        v = float4{o[0], o[1], o[2], o[3]};
+      }
+    }
+    *reinterpret_cast<float4*>(out + r * Ws + x) = v;
+  }
+}
+
+// Plane-per-workgroup-column variant for the odd widths of the deep levels (27, 54): one wave per 27-wide row left more
+// than half of the lanes idle and 590 000 rows made the launch itself the cost (183 -> 81 us for the 27-wide level at
+// batch 256).  blockIdx.x = (b, c) plane, blockIdx.y = chunk of the plane, a thread walks ~4 elements of its plane.
+__global__ __launch_bounds__(256) void upcat_fwd_plane_kernel(const float* __restrict__ x1, const float* __restrict__ skip,
+                                                              float* __restrict__ out, int B, int C1, int H1, int W1,
+                                                              int Cs, int Hs, int Ws) {
+  const int Ct = Cs + C1;
+  const int per_plane = Hs * Ws;
+  const int UH = 2 * H1, UW = 2 * W1;
+  const int padT = (Hs - UH) / 2, padL = (Ws - UW) / 2;
+  const long bc = blockIdx.x;
+  const int b = (int)(bc / Ct);
+  const int c = (int)(bc - (long)b * Ct);
+  float* oplane = out + bc * per_plane;
+  if (c < Cs) {
+    const float* splane = skip + ((long)b * Cs + c) * per_plane;
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < per_plane; i += gridDim.y * 256) oplane[i] = splane[i];
+    return;
+  }
+  const float* xplane = x1 + ((long)b * C1 + (c - Cs)) * H1 * W1;
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < per_plane; i += gridDim.y * 256) {
+    const int y = i / Ws;
+    const int x = i - y * Ws;
+    const int uy = y - padT, ux = x - padL;
+    float v = 0.f;
+    if (uy >= 0 && uy < UH && ux >= 0 && ux < UW) {
+      int y0, y1, x0, x1i;
+      float ly, lx;
+      bilin_src(uy, H1, UH, y0, y1, ly);
+      bilin_src(ux, W1, UW, x0, x1i, lx);
+      const float hy = 1.f - ly, hx = 1.f - lx;
+      const float* p0 = xplane + y0 * W1;
+      const float* p1 = xplane + y1 * W1;
+      v = hy * (hx * p0[x0] + lx * p0[x1i]) + ly * (hx * p1[x0] + lx * p1[x1i]);
+    }
+    oplane[i] = v;
+  }
+}
+
+// dx1 element by element, one thread each (the narrow deep levels: a wave per 13- or 27-wide row leaves most lanes idle)
+__global__ __launch_bounds__(256) void upcat_bwd_flat_kernel(const float* __restrict__ dout, float* __restrict__ dx1, int B,
+                                                             int C1, int H1, int W1, int Cs, int Hs, int Ws) {
+  const int Ct = Cs + C1;
+  const int UH = 2 * H1, UW = 2 * W1;
+  const int padT = (Hs - UH) / 2, padL = (Ws - UW) / 2;
+  const long total = (long)B * C1 * H1 * W1;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long k = e / W1;
+    const int j = (int)(e - k * W1);
+    const long bc = k / H1;
+    const int ii = (int)(k - bc * H1);
+    const int b = (int)(bc / C1);
+    const int c = (int)(bc - (long)b * C1);
+    const float* dp = dout + (((long)b * Ct + Cs + c) * Hs) * Ws;
+    float s = 0.f;
+    // same order of additions as upcat_bwd_kernel: columns outer, rows inner
+    const int ux_lo = max(0, 2 * j - 2), ux_hi = min(UW - 1, 2 * j + 3);
+    const int uy_lo = max(0, 2 * ii - 2), uy_hi = min(UH - 1, 2 * ii + 3);
+    for (int ux = ux_lo; ux <= ux_hi; ++ux) {
+      int x0, x1i;
+      float lx;
+      bilin_src(ux, W1, UW, x0, x1i, lx);
+      float wx = 0.f;
+      if (x0 == j) wx += 1.f - lx;
+      if (x1i == j) wx += lx;
+      const int ox = ux + padL;
+      if (wx == 0.f || ox < 0 || ox >= Ws) continue;
+      for (int uy = uy_lo; uy <= uy_hi; ++uy) {
+        int y0, y1;
+        float ly;
+        bilin_src(uy, H1, UH, y0, y1, ly);
+        float wy = 0.f;
+        if (y0 == ii) wy += 1.f - ly;
+        if (y1 == ii) wy += ly;
+        const int oy = uy + padT;
+        if (wy == 0.f || oy < 0 || oy >= Hs) continue;
+        s += wy * wx * dp[oy * Ws + ox];
+      }
+    }
+    dx1[e] = s;
+  }
+}
+
 // dskip = dout[:, :Cs]; dx1[i,j] = sum over upsampled positions that read (i,j).  One wave per row: first the
 // B*Cs*Hs skip rows, then the B*C1*H1 rows of dx1.
 __global__ __launch_bounds__(256) void upcat_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx1,
@@ -353,6 +485,86 @@ __global__ __launch_bounds__(256) void upcat_bwd_kernel(const float* __restrict_
       }
       dx1[k * W1 + j] = s;
     }
+  }
+}
+
+// Separable form of the dx1 gather (W1 <= 128, Ws <= 256): bilinear upsampling is Uy (x) Ux, so its transpose is
+// dx1 = Uy^T dU Ux.  One wave per source row ii: (1) t[ox] = sum over the <= 6 upsampled rows that read ii of
+// wy * dU[oy][ox] -- coalesced row reads, the row weights are wave-uniform; t goes to the wave's LDS row;
+// (2) dx1[ii][j] = sum over the <= 6 columns that read j of wx * t[ox], with the lane's column weights computed once
+// per kernel instead of once per element (the element-wise form spent its time in 36 index computations per output).
+__global__ __launch_bounds__(256) void upcat_bwd_sep_kernel(const float* __restrict__ dout, float* __restrict__ dx1, int B,
+                                                            int C1, int H1, int W1, int Cs, int Hs, int Ws) {
+  __shared__ float trow[4][256];
+  const int Ct = Cs + C1;
+  const int UH = 2 * H1, UW = 2 * W1;
+  const int padT = (Hs - UH) / 2, padL = (Ws - UW) / 2;
+  const long rx1 = (long)B * C1 * H1;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // this lane's columns j = lane, lane + 64: the upsampled columns that read j, as LDS index and weight
+  float wxs[2][6];
+  int oxs[2][6];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int j = lane + 64 * q;
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int ux = 2 * j - 2 + u;
+      float wx = 0.f;
+      int ox = 0;
+      if (j < W1 && ux >= 0 && ux < UW) {
+        int x0, x1i;
+        float lx;
+        bilin_src(ux, W1, UW, x0, x1i, lx);
+        if (x0 == j) wx += 1.f - lx;
+        if (x1i == j) wx += lx;
+        ox = ux + padL;
+        if (ox < 0 || ox >= Ws) { wx = 0.f; ox = 0; }
+      }
+      wxs[q][u] = wx; oxs[q][u] = ox;
+    }
+  }
+  float* t = trow[wave];
+  for (long k = (long)blockIdx.x * 4 + wave; k < rx1; k += (long)gridDim.x * 4) {
+    const long bc = k / H1;
+    const int ii = (int)(k - bc * H1);
+    const int b = (int)(bc / C1);
+    const int c = (int)(bc - (long)b * C1);
+    const float* dp = dout + (((long)b * Ct + Cs + c) * Hs) * Ws;
+    float wys[6];
+    int oys[6];
+    int nwy = 0;
+    const int uy_lo = max(0, 2 * ii - 2), uy_hi = min(UH - 1, 2 * ii + 3);
+    for (int uy = uy_lo; uy <= uy_hi; ++uy) {
+      int y0, y1;
+      float ly;
+      bilin_src(uy, H1, UH, y0, y1, ly);
+      float wy = 0.f;
+      if (y0 == ii) wy += 1.f - ly;
+      if (y1 == ii) wy += ly;
+      const int oy = uy + padT;
+      if (wy == 0.f || oy < 0 || oy >= Hs) continue;
+      wys[nwy] = wy; oys[nwy] = oy; ++nwy;
+    }
+    for (int x = lane; x < Ws; x += 64) {
+      float a = 0.f;
+      for (int tt = 0; tt < nwy; ++tt) a += wys[tt] * dp[oys[tt] * Ws + x];
+      t[x] = a;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the wave's own LDS writes are visible to all its lanes
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int j = lane + 64 * q;
+      if (j < W1) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) sacc += wxs[q][u] != 0.f ? wxs[q][u] * t[oxs[q][u]] : 0.f;   // (0 * inf stays out)
+        dx1[k * W1 + j] = sacc;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);      // reads done before the next row overwrites t
   }
 }
 
@@ -424,6 +636,18 @@ int mpa_maxpool2d_bwd(const float* dy, const int32_t* idx, float* dx, int B, int
 int mpa_upcat_fwd(const float* x1, const float* skip, float* out, int B, int C1, int H1, int W1, int Cs, int Hs, int Ws,
                   void* stream) {
   if (!x1 || !skip || !out || Hs < 2 * H1 || Ws < 2 * W1) return MPA_ERR_ARG;
+  if (Ws % 4 == 0 && (((uintptr_t)skip | (uintptr_t)out) & 15) == 0) {
+    const long quads = (long)B * (Cs + C1) * Hs * (Ws / 4);
+    MPA_LAUNCH(upcat_fwd4_kernel, dim3(blocks_for(quads)), dim3(256), 0, (hipStream_t)stream, x1, skip, out, B, C1, H1, W1,
+               Cs, Hs, Ws);
+    return mpa_launch_status();
+  }
+  const long planes = (long)B * (Cs + C1);
+  if (planes <= 0x7fffffffL && (long)Hs * Ws < (1L << 30)) {
+    const dim3 grid((unsigned)planes, (unsigned)std::max<long>(1, std::min<long>(mpa_cdiv((long)Hs * Ws, 1024), 64)));
+    MPA_LAUNCH(upcat_fwd_plane_kernel, grid, dim3(256), 0, (hipStream_t)stream, x1, skip, out, B, C1, H1, W1, Cs, Hs, Ws);
+    return mpa_launch_status();
+  }
   MPA_LAUNCH(upcat_fwd_kernel, dim3(row_blocks((long)B * (Cs + C1) * Hs)), dim3(256), 0, (hipStream_t)stream, x1,
                      skip, out, B, C1, H1, W1, Cs, Hs, Ws);
   return mpa_launch_status();
@@ -441,8 +665,15 @@ int mpa_upcat_bwd(const float* dout, float* dx1, float* dskip, int B, int C1, in
     MPA_LAUNCH(upcat_bwd_skip_kernel, dim3(bx, (unsigned)B), dim3(256), 0, (hipStream_t)stream, dout, dskip, per_b_skip,
                per_b_out);
     const long rskip = (long)B * Cs * Hs, rx1 = (long)B * C1 * H1;
-    MPA_LAUNCH(upcat_bwd_kernel, dim3(row_blocks(rx1)), dim3(256), 0, (hipStream_t)stream, dout, dx1, dskip, B, C1, H1, W1,
-               Cs, Hs, Ws, rskip);
+    if (W1 < 32)
+      MPA_LAUNCH(upcat_bwd_flat_kernel, dim3(blocks_for(rx1 * W1)), dim3(256), 0, (hipStream_t)stream, dout, dx1, B, C1, H1, W1,
+                 Cs, Hs, Ws);
+    else if (W1 <= 128 && Ws <= 256)
+      MPA_LAUNCH(upcat_bwd_sep_kernel, dim3(row_blocks(rx1)), dim3(256), 0, (hipStream_t)stream, dout, dx1, B, C1, H1, W1, Cs,
+                 Hs, Ws);
+    else
+      MPA_LAUNCH(upcat_bwd_kernel, dim3(row_blocks(rx1)), dim3(256), 0, (hipStream_t)stream, dout, dx1, dskip, B, C1, H1, W1,
+                 Cs, Hs, Ws, rskip);
     return mpa_launch_status();
   }
   const long n = (long)B * Cs * Hs + (long)B * C1 * H1;

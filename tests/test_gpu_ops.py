@@ -225,7 +225,8 @@ def test_maxpool_ties_first_max(dev):
 
 
 @pytest.mark.parametrize("g", [(2, 16, 4, 13, 16, 9, 27), (2, 8, 9, 27, 4, 18, 54), (1, 4, 18, 54, 4, 37, 108),
-                               (2, 4, 37, 108, 2, 75, 216), (1, 3, 10, 13, 2, 21, 27), (1, 2, 1, 1, 1, 3, 3)])
+                               (2, 4, 37, 108, 2, 75, 216), (1, 3, 10, 13, 2, 21, 27), (1, 2, 1, 1, 1, 3, 3),
+                               (2, 3, 10, 13, 2, 23, 32), (1, 2, 5, 100, 3, 11, 204), (1, 2, 3, 130, 1, 6, 260)])
 def test_upconcat(dev, g):
     from multipitch_architectures_amd import ops
     B, C1, H1, W1, Cs, Hs, Ws = g
