@@ -131,15 +131,17 @@ int mpa_act_bwd(const float* dy, const float* x, float* dx, int64_t n, int act, 
 /* rng_state (device memory): [0] seed, [1] base offset of the current training step; `offset` = position of this call's
  * elements inside the step.  Element i draws from the counter-based stream at rng_state[1] + offset + i.        */
 int mpa_dropout(const float* x, float* y, int64_t n, float p, const uint64_t* rng_state, uint64_t offset, void* stream);
-/* The CNN families' prefilter tail in one pass: nn.MaxPool2d((3,1), stride 1, padding (1,0)) -> nn.Dropout(p)
- * (basic_cnns.py:374-377) [-> + residual, deep_cnn_segm_sigmoid.forward basic_cnns.py:414-418].  h, out, residual:
- * [planes][H][W] fp32; residual may be NULL; p == 0 (evaluation) skips the mask and needs no rng_state.  The mask is
- * mpa_dropout's for the same (rng_state, offset).  which ([planes][H][W] int8, may be NULL when no gradient is needed)
- * records the window row 0..2 of each maximum for mpa_pool3_dropout_bwd, which returns d/dh (d/dresidual is dout). */
-int mpa_pool3_dropout_add_fwd(const float* h, const float* residual, float* out, int8_t* which, int64_t planes, int H, int W,
-                              float p, const uint64_t* rng_state, uint64_t offset, void* stream);
-int mpa_pool3_dropout_bwd(const float* dout, const int8_t* which, float* dh, int64_t planes, int H, int W, float p,
-                          const uint64_t* rng_state, uint64_t offset, void* stream);
+/* nn.MaxPool2d((kh,1), stride 1, padding (kh/2,0)) -> nn.Dropout(p) [-> + residual] in one pass, kh = 3 or 13: the tail
+ * of the CNN families' prefilter stages (kh = 3, basic_cnns.py:374-377; the residual of deep_cnn_segm_sigmoid.forward,
+ * basic_cnns.py:414-418) and of every model's head stage conv2 (kh = 13, basic_cnns.py:380-385, unet_cnns.py:538-543).
+ * h, out, residual: [planes][H][W] fp32; residual may be NULL; p == 0 (evaluation) skips the mask and needs no rng_state.
+ * The mask is mpa_dropout's for the same (rng_state, offset).  which ([planes][H][W] int8, may be NULL when no gradient
+ * is needed) records the window row 0..kh-1 of each maximum for mpa_poolrows_dropout_bwd, which returns d/dh
+ * (d/dresidual is dout).  Other kh: MPA_ERR_UNSUPPORTED. */
+int mpa_poolrows_dropout_add_fwd(const float* h, const float* residual, float* out, int8_t* which, int64_t planes, int H,
+                                 int W, int kh, float p, const uint64_t* rng_state, uint64_t offset, void* stream);
+int mpa_poolrows_dropout_bwd(const float* dout, const int8_t* which, float* dh, int64_t planes, int H, int W, int kh, float p,
+                             const uint64_t* rng_state, uint64_t offset, void* stream);
 /* table[i] = host_ptrs[i], i < n: device pointer table written by kernels whose arguments carry the pointers (no
  * memcpy, nothing for the host to keep alive; capturable in a HIP graph)                                       */
 int mpa_store_ptrs(const void** table, const void* const* host_ptrs, int n, void* stream);

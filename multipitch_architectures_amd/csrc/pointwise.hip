@@ -76,18 +76,20 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
   }
 }
 
-// The CNN families' prefilter tail -- MaxPool2d((3,1), stride 1, padding (1,0)) -> Dropout [-> + residual]
-// (basic_cnns.py:374-377 and the residual add of deep_cnn_segm_sigmoid.forward, :414-418) -- as one pass over the
-// activations instead of three (pool with an int32 argmax plane, dropout, add: 2.6 GB of traffic per 290 MB tensor,
-// against 0.94 GB here).  A thread owns V adjacent columns and R consecutive rows: it loads the R + 2 input rows once
+// MaxPool2d((KH,1), stride 1, padding (KH/2, 0)) -> Dropout [-> + residual] in one pass: the tail of the CNN families'
+// prefilter stages (KH = 3, basic_cnns.py:374-377, with the residual add of deep_cnn_segm_sigmoid.forward, :414-418) and
+// of every model's head stage conv2 (KH = 13, basic_cnns.py:380-385 / unet_cnns.py:538-543).  Instead of three passes
+// (pool with an int32 argmax plane, dropout, add: 2.6 GB of traffic per 290 MB tensor) the activations cross HBM once
+// each way (0.94 GB).  A thread owns V adjacent columns and R consecutive rows: it loads the R + KH - 1 input rows once
 // and forms the R windows in registers.  Same rules as the separate kernels, bit for bit: first maximum wins and a NaN
 // propagates (maxpool_fwd_plane_kernel), the keep mask is rng_uniform(seed, base + offset + flat index) >= p
-// (dropout_kernel), and the sum is (pooled * scale) + residual.  `which` records the window row (0..2) of the maximum.
-template <int R, int V>
-__global__ __launch_bounds__(256) void pool3_drop_add_fwd_kernel(const float* __restrict__ h, const float* __restrict__ res,
-                                                                 float* __restrict__ out, int8_t* __restrict__ which,
-                                                                 long planes, int H, int W, float p, float scale,
-                                                                 const uint64_t* __restrict__ rng_state, uint64_t local) {
+// (dropout_kernel), and the sum is (pooled * scale) + residual.  `which` records the window row (0..KH-1) of the maximum.
+template <int KH, int R, int V>
+__global__ __launch_bounds__(256) void poolrows_drop_add_fwd_kernel(const float* __restrict__ h, const float* __restrict__ res,
+                                                                    float* __restrict__ out, int8_t* __restrict__ which,
+                                                                    long planes, int H, int W, float p, float scale,
+                                                                    const uint64_t* __restrict__ rng_state, uint64_t local) {
+  constexpr int PAD = KH / 2;
   const int WV = W / V, nblk = (H + R - 1) / R;
   const long items = planes * nblk * WV;
   const bool drop = p > 0.f;
@@ -98,17 +100,19 @@ __global__ __launch_bounds__(256) void pool3_drop_add_fwd_kernel(const float* __
     const long pl = pb / nblk;
     const int r0 = (int)(pb - pl * nblk) * R;
     const long base = pl * H * W + col;
-    float v[R + 2][V];
+    float v[R + KH - 1][V];
 #pragma unroll
-    for (int j = 0; j < R + 2; ++j) {
-      const int row = r0 - 1 + j;
+    for (int j = 0; j < R + KH - 1; ++j) {
+      const int row = r0 - PAD + j;
       if (row >= 0 && row < H) {
         if constexpr (V == 4) {
           const float4 t = *reinterpret_cast<const float4*>(h + base + (long)row * W);
           v[j][0] = t.x; v[j][1] = t.y; v[j][2] = t.z; v[j][3] = t.w;
+        } else if constexpr (V == 2) {
+          const float2 t = *reinterpret_cast<const float2*>(h + base + (long)row * W);
+          v[j][0] = t.x; v[j][1] = t.y;
         } else {
-#pragma unroll
-          for (int c = 0; c < V; ++c) v[j][c] = h[base + (long)row * W + c];
+          v[j][0] = h[base + (long)row * W];
         }
       } else {
 #pragma unroll
@@ -127,8 +131,8 @@ __global__ __launch_bounds__(256) void pool3_drop_add_fwd_kernel(const float* __
         float best = 0.f;
         int sel = -1;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          const int iy = row - 1 + d;
+        for (int d = 0; d < KH; ++d) {
+          const int iy = row - PAD + d;
           if (iy < 0 || iy >= H) continue;
           const float t = v[r + d][c];
           if (sel < 0 || t > best || t != t) { best = t; sel = d; }
@@ -141,21 +145,25 @@ __global__ __launch_bounds__(256) void pool3_drop_add_fwd_kernel(const float* __
       if constexpr (V == 4) {
         *reinterpret_cast<float4*>(out + e) = float4{o[0], o[1], o[2], o[3]};
         if (which) *reinterpret_cast<char4*>(which + e) = char4{wsel[0], wsel[1], wsel[2], wsel[3]};
+      } else if constexpr (V == 2) {
+        *reinterpret_cast<float2*>(out + e) = float2{o[0], o[1]};
+        if (which) *reinterpret_cast<char2*>(which + e) = char2{wsel[0], wsel[1]};
       } else {
-#pragma unroll
-        for (int c = 0; c < V; ++c) { out[e + c] = o[c]; if (which) which[e + c] = wsel[c]; }
+        out[e] = o[0];
+        if (which) which[e] = wsel[0];
       }
     }
   }
 }
 
 // Backward of the pool + dropout part (the residual's gradient is dout itself): gather form, fixed order -- input row
-// rho collects g(r) = keep(r) * scale * dout(r) from the windows r = rho + 1, rho, rho - 1 whose recorded row is rho.
-template <int R, int V>
-__global__ __launch_bounds__(256) void pool3_drop_bwd_kernel(const float* __restrict__ dout, const int8_t* __restrict__ which,
-                                                             float* __restrict__ dh, long planes, int H, int W, float p,
-                                                             float scale, const uint64_t* __restrict__ rng_state,
-                                                             uint64_t local) {
+// rho collects g(r) = keep(r) * scale * dout(r) from the windows r = rho + PAD ... rho - PAD whose recorded row is rho.
+template <int KH, int R, int V>
+__global__ __launch_bounds__(256) void poolrows_drop_bwd_kernel(const float* __restrict__ dout, const int8_t* __restrict__ which,
+                                                                float* __restrict__ dh, long planes, int H, int W, float p,
+                                                                float scale, const uint64_t* __restrict__ rng_state,
+                                                                uint64_t local) {
+  constexpr int PAD = KH / 2;
   const int WV = W / V, nblk = (H + R - 1) / R;
   const long items = planes * nblk * WV;
   const bool drop = p > 0.f;
@@ -166,11 +174,11 @@ __global__ __launch_bounds__(256) void pool3_drop_bwd_kernel(const float* __rest
     const long pl = pb / nblk;
     const int r0 = (int)(pb - pl * nblk) * R;
     const long base = pl * H * W + col;
-    float g[R + 2][V];
-    int8_t w[R + 2][V];
+    float g[R + KH - 1][V];
+    int8_t w[R + KH - 1][V];
 #pragma unroll
-    for (int j = 0; j < R + 2; ++j) {
-      const int row = r0 - 1 + j;
+    for (int j = 0; j < R + KH - 1; ++j) {
+      const int row = r0 - PAD + j;      // window (= output) row
       if (row >= 0 && row < H) {
         const long e = base + (long)row * W;
         if constexpr (V == 4) {
@@ -178,9 +186,13 @@ __global__ __launch_bounds__(256) void pool3_drop_bwd_kernel(const float* __rest
           const char4 s = *reinterpret_cast<const char4*>(which + e);
           g[j][0] = t.x; g[j][1] = t.y; g[j][2] = t.z; g[j][3] = t.w;
           w[j][0] = s.x; w[j][1] = s.y; w[j][2] = s.z; w[j][3] = s.w;
+        } else if constexpr (V == 2) {
+          const float2 t = *reinterpret_cast<const float2*>(dout + e);
+          const char2 s = *reinterpret_cast<const char2*>(which + e);
+          g[j][0] = t.x; g[j][1] = t.y;
+          w[j][0] = s.x; w[j][1] = s.y;
         } else {
-#pragma unroll
-          for (int c = 0; c < V; ++c) { g[j][c] = dout[e + c]; w[j][c] = which[e + c]; }
+          g[j][0] = dout[e]; w[j][0] = which[e];
         }
         if (drop) {
 #pragma unroll
@@ -198,19 +210,17 @@ __global__ __launch_bounds__(256) void pool3_drop_bwd_kernel(const float* __rest
       float o[V];
 #pragma unroll
       for (int c = 0; c < V; ++c) {
-        // window r = rho + 1 holds rho as its row 0, window rho as its row 1, window rho - 1 as its row 2
+        // window rho + PAD - d holds rho as its row d (register row r + 2 PAD - d)
         float a = 0.f;
-        if (w[r + 2][c] == 0) a += g[r + 2][c];
-        if (w[r + 1][c] == 1) a += g[r + 1][c];
-        if (w[r][c] == 2) a += g[r][c];
+#pragma unroll
+        for (int d = 0; d < KH; ++d)
+          if (w[r + 2 * PAD - d][c] == d) a += g[r + 2 * PAD - d][c];
         o[c] = a;
       }
       const long e = base + (long)row * W;
       if constexpr (V == 4) *reinterpret_cast<float4*>(dh + e) = float4{o[0], o[1], o[2], o[3]};
-      else {
-#pragma unroll
-        for (int c = 0; c < V; ++c) dh[e + c] = o[c];
-      }
+      else if constexpr (V == 2) *reinterpret_cast<float2*>(dh + e) = float2{o[0], o[1]};
+      else dh[e] = o[0];
     }
   }
 }
@@ -474,6 +484,48 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* const* __restrict__ p
   }
 }
 
+template <int KH, int R>
+int poolrows_fwd_launch(const float* h, const float* residual, float* out, int8_t* which, long planes, int H, int W, float p,
+                        const uint64_t* rng_state, uint64_t offset, hipStream_t s) {
+  const float scale = 1.f / (1.f - p);
+  const uintptr_t al = (uintptr_t)h | (uintptr_t)out | (uintptr_t)residual | (uintptr_t)which;
+  constexpr int VMAX = KH == 3 ? 4 : 2;      // the 13-row window keeps R + 12 rows per column in registers
+  const int V = (VMAX == 4 && W % 4 == 0 && (al & 15) == 0) ? 4 : ((W % 2 == 0 && (al & 7) == 0) ? 2 : 1);
+  const long items = planes * mpa_cdiv(H, R) * (W / V);
+  if (V == 4) {
+    if constexpr (VMAX == 4)
+      MPA_LAUNCH((poolrows_drop_add_fwd_kernel<KH, R, 4>), dim3(blocks_for(items)), dim3(256), 0, s, h, residual, out, which, planes,
+                 H, W, p, scale, rng_state, offset);
+  } else if (V == 2) {
+    MPA_LAUNCH((poolrows_drop_add_fwd_kernel<KH, R, 2>), dim3(blocks_for(items)), dim3(256), 0, s, h, residual, out, which, planes,
+               H, W, p, scale, rng_state, offset);
+  } else {
+    MPA_LAUNCH((poolrows_drop_add_fwd_kernel<KH, R, 1>), dim3(blocks_for(items)), dim3(256), 0, s, h, residual, out, which, planes,
+               H, W, p, scale, rng_state, offset);
+  }
+  return mpa_launch_status();
+}
+template <int KH, int R>
+int poolrows_bwd_launch(const float* dout, const int8_t* which, float* dh, long planes, int H, int W, float p,
+                        const uint64_t* rng_state, uint64_t offset, hipStream_t s) {
+  const float scale = 1.f / (1.f - p);
+  const uintptr_t al = (uintptr_t)dout | (uintptr_t)dh | (uintptr_t)which;
+  constexpr int VMAX = KH == 3 ? 4 : 2;
+  const int V = (VMAX == 4 && W % 4 == 0 && (al & 15) == 0) ? 4 : ((W % 2 == 0 && (al & 7) == 0) ? 2 : 1);
+  const long items = planes * mpa_cdiv(H, R) * (W / V);
+  if (V == 4) {
+    if constexpr (VMAX == 4)
+      MPA_LAUNCH((poolrows_drop_bwd_kernel<KH, R, 4>), dim3(blocks_for(items)), dim3(256), 0, s, dout, which, dh, planes, H, W, p,
+                 scale, rng_state, offset);
+  } else if (V == 2) {
+    MPA_LAUNCH((poolrows_drop_bwd_kernel<KH, R, 2>), dim3(blocks_for(items)), dim3(256), 0, s, dout, which, dh, planes, H, W, p,
+               scale, rng_state, offset);
+  } else {
+    MPA_LAUNCH((poolrows_drop_bwd_kernel<KH, R, 1>), dim3(blocks_for(items)), dim3(256), 0, s, dout, which, dh, planes, H, W, p,
+               scale, rng_state, offset);
+  }
+  return mpa_launch_status();
+}
 }  // namespace
 
 extern "C" {
@@ -509,38 +561,22 @@ int mpa_dropout(const float* x, float* y, int64_t n, float p, const uint64_t* rn
                      rng_state, offset);
   return mpa_launch_status();
 }
-int mpa_pool3_dropout_add_fwd(const float* h, const float* residual, float* out, int8_t* which, int64_t planes, int H, int W,
-                              float p, const uint64_t* rng_state, uint64_t offset, void* stream) {
+int mpa_poolrows_dropout_add_fwd(const float* h, const float* residual, float* out, int8_t* which, int64_t planes, int H,
+                                 int W, int kh, float p, const uint64_t* rng_state, uint64_t offset, void* stream) {
   if (!h || !out || planes < 0 || H <= 0 || W <= 0 || p < 0.f || p >= 1.f || (p > 0.f && !rng_state)) return MPA_ERR_ARG;
+  if (kh != 3 && kh != 13) return MPA_ERR_UNSUPPORTED;
   if (planes == 0) return MPA_OK;
-  const float scale = 1.f / (1.f - p);
-  constexpr int R = 15;
-  const bool quad = W % 4 == 0 && (((uintptr_t)h | (uintptr_t)out | (uintptr_t)residual | (uintptr_t)which) & 15) == 0;
-  const long items = planes * mpa_cdiv(H, R) * (quad ? W / 4 : W);
-  if (quad)
-    MPA_LAUNCH((pool3_drop_add_fwd_kernel<R, 4>), dim3(blocks_for(items)), dim3(256), 0, (hipStream_t)stream, h, residual, out,
-               which, (long)planes, H, W, p, scale, rng_state, offset);
-  else
-    MPA_LAUNCH((pool3_drop_add_fwd_kernel<R, 1>), dim3(blocks_for(items)), dim3(256), 0, (hipStream_t)stream, h, residual, out,
-               which, (long)planes, H, W, p, scale, rng_state, offset);
-  return mpa_launch_status();
+  if (kh == 3) return poolrows_fwd_launch<3, 15>(h, residual, out, which, (long)planes, H, W, p, rng_state, offset, (hipStream_t)stream);
+  return poolrows_fwd_launch<13, 12>(h, residual, out, which, (long)planes, H, W, p, rng_state, offset, (hipStream_t)stream);
 }
-int mpa_pool3_dropout_bwd(const float* dout, const int8_t* which, float* dh, int64_t planes, int H, int W, float p,
-                          const uint64_t* rng_state, uint64_t offset, void* stream) {
+int mpa_poolrows_dropout_bwd(const float* dout, const int8_t* which, float* dh, int64_t planes, int H, int W, int kh, float p,
+                             const uint64_t* rng_state, uint64_t offset, void* stream) {
   if (!dout || !which || !dh || planes < 0 || H <= 0 || W <= 0 || p < 0.f || p >= 1.f || (p > 0.f && !rng_state))
     return MPA_ERR_ARG;
+  if (kh != 3 && kh != 13) return MPA_ERR_UNSUPPORTED;
   if (planes == 0) return MPA_OK;
-  const float scale = 1.f / (1.f - p);
-  constexpr int R = 15;
-  const bool quad = W % 4 == 0 && (((uintptr_t)dout | (uintptr_t)dh | (uintptr_t)which) & 15) == 0;
-  const long items = planes * mpa_cdiv(H, R) * (quad ? W / 4 : W);
-  if (quad)
-    MPA_LAUNCH((pool3_drop_bwd_kernel<R, 4>), dim3(blocks_for(items)), dim3(256), 0, (hipStream_t)stream, dout, which, dh,
-               (long)planes, H, W, p, scale, rng_state, offset);
-  else
-    MPA_LAUNCH((pool3_drop_bwd_kernel<R, 1>), dim3(blocks_for(items)), dim3(256), 0, (hipStream_t)stream, dout, which, dh,
-               (long)planes, H, W, p, scale, rng_state, offset);
-  return mpa_launch_status();
+  if (kh == 3) return poolrows_bwd_launch<3, 15>(dout, which, dh, (long)planes, H, W, p, rng_state, offset, (hipStream_t)stream);
+  return poolrows_bwd_launch<13, 12>(dout, which, dh, (long)planes, H, W, p, rng_state, offset, (hipStream_t)stream);
 }
 int mpa_store_ptrs(const void** table, const void* const* host_ptrs, int n, void* stream) {
   if (!table || !host_ptrs || n < 0) return MPA_ERR_ARG;

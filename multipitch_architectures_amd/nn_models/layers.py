@@ -219,10 +219,11 @@ class ConvActPoolDrop(nn.Sequential):
         conv, act = mods[0], mods[1]
         h = conv(x, act.act, act.slope)
         rest = mods[2:]
-        if (len(rest) == 2 and isinstance(rest[0], MaxPool2d) and isinstance(rest[1], Dropout)
-                and (rest[0].kernel_size, rest[0].stride, rest[0].padding) == ((3, 1), (1, 1), (1, 0))):
-            # the prefilter tail (pool over 3 frames, dropout, residual add) is one kernel
-            return ops.pool3_dropout_add(h, residual, rest[1].p, self.training)
+        if len(rest) == 2 and isinstance(rest[0], MaxPool2d) and isinstance(rest[1], Dropout):
+            (kh, kw), pool = rest[0].kernel_size, rest[0]
+            if kw == 1 and kh in ops.POOLROWS_KH and pool.stride == (1, 1) and pool.padding == (kh // 2, 0):
+                # the stage's tail (pool over 3 / 13 frames, dropout, residual add) is one kernel
+                return ops.poolrows_dropout_add(h, residual, kh, rest[1].p, self.training)
         for m in rest:
             h = m(h)
         return h if residual is None else ops.add(h, residual)

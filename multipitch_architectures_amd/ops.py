@@ -480,30 +480,31 @@ def dropout(x, p, training):
     return DropoutFn.apply(x, p)
 
 
-class Pool3DropAddFn(torch.autograd.Function):
-    """MaxPool2d((3,1), stride 1, padding (1,0)) -> Dropout(p) [-> + residual] in one pass: the tail of the CNN families'
-    prefilter stages (basic_cnns.py:374-377) and the residual add of deep_cnn_segm_sigmoid.forward (:414-418).  Same
-    masks and the same position in the dropout stream as max_pool2d + dropout + add."""
+class PoolRowsDropAddFn(torch.autograd.Function):
+    """MaxPool2d((kh,1), stride 1, padding (kh//2,0)) -> Dropout(p) [-> + residual] in one pass, kh = 3 or 13: the tail of
+    the CNN families' prefilter stages (basic_cnns.py:374-377, with the residual add of deep_cnn_segm_sigmoid.forward,
+    :414-418) and of every model's head stage conv2 (basic_cnns.py:380-385, unet_cnns.py:538-543).  Same masks and the same
+    position in the dropout stream as max_pool2d + dropout + add."""
 
     @staticmethod
-    def forward(ctx, h, residual, p):
+    def forward(ctx, h, residual, kh, p):
         h = _c(h)
         B, C, H, W = h.shape
         if residual is not None:
             residual = _c(residual)
             if residual.shape != h.shape:
-                raise RuntimeError(f"pool3_dropout_add: shape mismatch {tuple(h.shape)} vs {tuple(residual.shape)}")
+                raise RuntimeError(f"poolrows_dropout_add: shape mismatch {tuple(h.shape)} vs {tuple(residual.shape)}")
         out = torch.empty_like(h)
         need = ctx.needs_input_grad[0]
         which = torch.empty(h.shape, dtype=torch.int8, device=h.device) if need else None
-        ctx.p = float(p)
+        ctx.p, ctx.kh = float(p), int(kh)
         ctx.state, ctx.offset = (_rng_state(h.device), _Rng.local) if ctx.p > 0.0 else (None, 0)
         if ctx.p > 0.0:
             _Rng.local += h.numel()
-        _chk(_lib().mpa_pool3_dropout_add_fwd(_p(h), _p(residual) if residual is not None else None, _p(out),
-                                             ctypes.c_void_p(which.data_ptr()) if need else None, B * C, H, W, ctx.p,
-                                             _p(ctx.state) if ctx.state is not None else None, ctx.offset, _s()),
-             "mpa_pool3_dropout_add_fwd")
+        _chk(_lib().mpa_poolrows_dropout_add_fwd(_p(h), _p(residual) if residual is not None else None, _p(out),
+                                                ctypes.c_void_p(which.data_ptr()) if need else None, B * C, H, W, ctx.kh,
+                                                ctx.p, _p(ctx.state) if ctx.state is not None else None, ctx.offset,
+                                                _s()), "mpa_poolrows_dropout_add_fwd")
         ctx.has_res = residual is not None
         ctx.save_for_backward(which)
         return out
@@ -516,20 +517,25 @@ class Pool3DropAddFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             B, C, H, W = dout.shape
             dh = torch.empty_like(dout)
-            _chk(_lib().mpa_pool3_dropout_bwd(_p(dout), ctypes.c_void_p(which.data_ptr()), _p(dh), B * C, H, W, ctx.p,
-                                             _p(ctx.state) if ctx.state is not None else None, ctx.offset, _s()),
-                 "mpa_pool3_dropout_bwd")
-        return dh, (dout if ctx.has_res and ctx.needs_input_grad[1] else None), None
+            _chk(_lib().mpa_poolrows_dropout_bwd(_p(dout), ctypes.c_void_p(which.data_ptr()), _p(dh), B * C, H, W, ctx.kh,
+                                                ctx.p, _p(ctx.state) if ctx.state is not None else None, ctx.offset,
+                                                _s()), "mpa_poolrows_dropout_bwd")
+        return dh, (dout if ctx.has_res and ctx.needs_input_grad[1] else None), None, None
 
 
-def pool3_dropout_add(h, residual, p, training):
-    """dropout(max_pool2d(h, (3,1), (1,1), (1,0)), p) [+ residual]"""
+POOLROWS_KH = (3, 13)      # window heights the fused kernels are built for
+
+
+def poolrows_dropout_add(h, residual, kh, p, training):
+    """dropout(max_pool2d(h, (kh,1), (1,1), (kh//2,0)), p) [+ residual]"""
     p = float(p) if training else 0.0
     if p >= 1.0:
         raise RuntimeError("dropout p must be < 1")
     if h.dim() != 4:
-        raise RuntimeError("pool3_dropout_add expects (B, C, H, W)")
-    return Pool3DropAddFn.apply(h, residual, p)
+        raise RuntimeError("poolrows_dropout_add expects (B, C, H, W)")
+    if kh not in POOLROWS_KH:
+        raise RuntimeError(f"poolrows_dropout_add is built for window heights {POOLROWS_KH}, got {kh}")
+    return PoolRowsDropAddFn.apply(h, residual, kh, p)
 
 
 class AddFn(torch.autograd.Function):

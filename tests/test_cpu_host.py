@@ -119,7 +119,7 @@ def test_cpu_tensors_raise_not_fallback():
         AdamW([p]).step()
     from multipitch_architectures_amd import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
-        ops.pool3_dropout_add(torch.zeros(1, 2, 5, 4), None, 0.2, True)
+        ops.poolrows_dropout_add(torch.zeros(1, 2, 5, 4), None, 3, 0.2, True)
 
 
 def test_sinusoidal_pe_not_in_state_dict_and_constructible_without_gpu():

@@ -681,14 +681,15 @@ def test_maxpool_head_window_nan_and_ties(dev):
     assert torch.equal(b.grad.cpu(), a.grad)
 
 
-@pytest.mark.parametrize("shape", [(2, 5, 75, 216), (3, 4, 7, 10), (1, 2, 1, 8), (2, 3, 31, 13), (1, 1, 2, 4)],
-                         ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("shape", [(2, 5, 75, 216), (3, 4, 7, 10), (1, 2, 1, 8), (2, 3, 31, 13), (1, 1, 2, 4), (2, 3, 75, 72),
+                                   (1, 2, 40, 6)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("kh", [3, 13])
 @pytest.mark.parametrize("p", [0.2, 0.0])
 @pytest.mark.parametrize("with_res", [True, False])
-def test_pool3_dropout_add_matches_the_three_separate_ops(dev, shape, p, with_res):
-    """the fused prefilter tail (MaxPool2d((3,1),1,(1,0)) -> Dropout -> + residual, basic_cnns.py:374-377,414-418) against
-    max_pool2d + dropout + add: same mask (same position in the dropout stream), outputs bit for bit, gradients to
-    rounding (the separate pool backward adds overlapping windows in no fixed order)"""
+def test_poolrows_dropout_add_matches_the_three_separate_ops(dev, shape, kh, p, with_res):
+    """the fused stage tail (MaxPool2d((kh,1),1,(kh//2,0)) -> Dropout -> + residual; kh = 3: basic_cnns.py:374-377,414-418,
+    kh = 13: the head's conv2 stage) against max_pool2d + dropout + add: same mask (same position in the dropout stream),
+    outputs bit for bit, gradients to rounding (the separate pool backward adds overlapping windows in no fixed order)"""
     from multipitch_architectures_amd import ops
     h = _rand(shape, 61)
     h[0, 0, 0, :3] = h[0, 0, min(1, shape[2] - 1), :3]        # ties: the first maximum must win
@@ -701,9 +702,9 @@ def test_pool3_dropout_add_matches_the_three_separate_ops(dev, shape, p, with_re
         rg = res.to(dev).requires_grad_(True) if with_res else None
         pre = ops.dropout(_rand((7,), 1).to(dev), 0.5, True)      # the tail does not start at stream position 0
         if fused:
-            y = ops.pool3_dropout_add(hg, rg, p, True)
+            y = ops.poolrows_dropout_add(hg, rg, kh, p, True)
         else:
-            y = ops.dropout(ops.max_pool2d(hg, (3, 1), (1, 1), (1, 0)), p, True)
+            y = ops.dropout(ops.max_pool2d(hg, (kh, 1), (1, 1), (kh // 2, 0)), p, True)
             if with_res:
                 y = ops.add(y, rg)
         post = ops.dropout(torch.ones(64, device=dev), 0.5, True)  # ... and leaves it where the separate ops do
@@ -718,20 +719,25 @@ def test_pool3_dropout_add_matches_the_three_separate_ops(dev, shape, p, with_re
     _close(dhf, dhu, 1e-6, "dh")
     if with_res:
         assert torch.equal(drf, dru)
-    # and against torch (pool + the mask recovered from the op itself)
-    ref = F.max_pool2d(h.double(), (3, 1), (1, 1), (1, 0))
-    if p == 0.0:
+    if p == 0.0:      # and against torch
+        ref = F.max_pool2d(h.double(), (kh, 1), (1, 1), (kh // 2, 0))
         _close(yf, ref + (res.double() if with_res else 0), 1e-6, "y vs torch")
+        hr = h.double().requires_grad_(True)
+        F.max_pool2d(hr, (kh, 1), (1, 1), (kh // 2, 0)).backward(gy.cpu().double())
+        _close(dhf, hr.grad, 1e-6, "dh vs torch")
 
 
-def test_pool3_dropout_add_nan_propagates_and_eval_mode(dev):
+@pytest.mark.parametrize("kh", [3, 13])
+def test_poolrows_dropout_add_nan_propagates_and_eval_mode(dev, kh):
     from multipitch_architectures_amd import ops
-    h = _rand((1, 2, 9, 8), 5)
+    h = _rand((1, 2, 19, 8), 5)
     h[0, 1, 4, 3] = float("nan")
-    y = ops.pool3_dropout_add(h.to(dev), None, 0.2, False)           # eval: no mask
-    ref = F.max_pool2d(h, (3, 1), (1, 1), (1, 0))
+    y = ops.poolrows_dropout_add(h.to(dev), None, kh, 0.2, False)           # eval: no mask
+    ref = F.max_pool2d(h, (kh, 1), (1, 1), (kh // 2, 0))
     assert torch.equal(torch.isnan(y.cpu()), torch.isnan(ref))
     ok = ~torch.isnan(ref)
     assert torch.equal(y.cpu()[ok], ref[ok])
     with pytest.raises(RuntimeError):
-        ops.pool3_dropout_add(h.to(dev), _rand((1, 2, 9, 4), 6).to(dev), 0.2, True)
+        ops.poolrows_dropout_add(h.to(dev), _rand((1, 2, 19, 4), 6).to(dev), kh, 0.2, True)
+    with pytest.raises(RuntimeError):
+        ops.poolrows_dropout_add(h.to(dev), None, 5, 0.2, True)
