@@ -17,17 +17,24 @@ __global__ __launch_bounds__(256) void layernorm_cf_fwd_kernel(const float* __re
   if (bt >= (long)B * T) return;
   const int b = (int)(bt / T), t = (int)(bt - (long)b * T);
   const int n = C * F;
+  const long rowbase = (long)b * C * T * F + (long)t * F;      // element (c, f) of the row sits at rowbase + c T F + f
+  // every lane loads all LNCF_MAXV slots unconditionally (slots past n re-read element 0 and are masked afterwards):
+  // guarded loads compile to one branch + wait per element, i.e. LNCF_MAXV serial trips to memory per row
   float v[LNCF_MAXV];
+  int off[LNCF_MAXV];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < LNCF_MAXV; ++i) {
-    const int e = i * 64 + lane;
-    v[i] = 0.f;
-    if (e < n) {
-      const int c = e / F, f = e - c * F;
-      v[i] = x[(((long)b * C + c) * T + t) * F + f];
-      s += v[i];
-    }
+    const int e = min(i * 64 + lane, n - 1);
+    const int c = e / F, f = e - c * F;
+    off[i] = c * T * F + f;
+  }
+#pragma unroll
+  for (int i = 0; i < LNCF_MAXV; ++i) v[i] = x[rowbase + off[i]];
+#pragma unroll
+  for (int i = 0; i < LNCF_MAXV; ++i) {
+    v[i] = i * 64 + lane < n ? v[i] : 0.f;
+    s += v[i];
   }
   const float mu = mpa_wave_sum(s) / (float)n;
   float q = 0.f;
@@ -40,10 +47,7 @@ __global__ __launch_bounds__(256) void layernorm_cf_fwd_kernel(const float* __re
 #pragma unroll
   for (int i = 0; i < LNCF_MAXV; ++i) {
     const int e = i * 64 + lane;
-    if (e < n) {
-      const int c = e / F, f = e - c * F;
-      y[(((long)b * C + c) * T + t) * F + f] = (v[i] - mu) * rs * w[e] + bb[e];
-    }
+    if (e < n) y[rowbase + off[i]] = (v[i] - mu) * rs * w[e] + bb[e];      // (w, bb: L1 hits)
   }
   if (lane == 0) { mean[bt] = mu; rstd[bt] = rs; }
 }
@@ -56,42 +60,43 @@ __global__ __launch_bounds__(256) void layernorm_cf_bwd_kernel(const float* __re
   extern __shared__ float sh[];   // [4][2][n] per-wave partials
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = C * F;
-  float pw[LNCF_MAXV], pb[LNCF_MAXV];
+  float pw[LNCF_MAXV], pb[LNCF_MAXV], wv[LNCF_MAXV];
+  int off[LNCF_MAXV];      // element (c, f) of a row sits at rowbase + c T F + f: the division by F once per kernel
 #pragma unroll
-  for (int i = 0; i < LNCF_MAXV; ++i) { pw[i] = 0.f; pb[i] = 0.f; }
+  for (int i = 0; i < LNCF_MAXV; ++i) {
+    pw[i] = 0.f; pb[i] = 0.f;
+    const int e = min(i * 64 + lane, n - 1);      // slots past n re-read the last element and are masked afterwards
+    const int c = e / F, f = e - c * F;
+    off[i] = c * T * F + f;
+    wv[i] = i * 64 + lane < n ? w[e] : 0.f;
+  }
   const long rows = (long)B * T;
   for (long bt = (long)blockIdx.x * 4 + wave; bt < rows; bt += (long)gridDim.x * 4) {
     const int b = (int)(bt / T), t = (int)(bt - (long)b * T);
     const float mu = mean[bt], rs = rstd[bt];
+    const long rowbase = (long)b * C * T * F + (long)t * F;
+    // all loads of the row first, unconditionally (a guarded load per element is a branch and a wait per element)
     float g[LNCF_MAXV], xh[LNCF_MAXV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
+    for (int i = 0; i < LNCF_MAXV; ++i) { g[i] = dy[rowbase + off[i]]; xh[i] = x[rowbase + off[i]]; }
+#pragma unroll
     for (int i = 0; i < LNCF_MAXV; ++i) {
-      const int e = i * 64 + lane;
-      g[i] = 0.f; xh[i] = 0.f;
-      if (e < n) {
-        const int c = e / F, f = e - c * F;
-        const long o = (((long)b * C + c) * T + t) * F + f;
-        const float d = dy[o];
-        xh[i] = (x[o] - mu) * rs;
-        pw[i] += d * xh[i];
-        pb[i] += d;
-        g[i] = d * w[e];
-        s1 += g[i];
-        s2 += g[i] * xh[i];
-      }
+      const bool on = i * 64 + lane < n;
+      const float d = on ? g[i] : 0.f;
+      xh[i] = on ? (xh[i] - mu) * rs : 0.f;
+      pw[i] += d * xh[i];
+      pb[i] += d;
+      g[i] = d * wv[i];
+      s1 += g[i];
+      s2 += g[i] * xh[i];
     }
     if (dx) {
       s1 = mpa_wave_sum(s1) / (float)n;
       s2 = mpa_wave_sum(s2) / (float)n;
 #pragma unroll
-      for (int i = 0; i < LNCF_MAXV; ++i) {
-        const int e = i * 64 + lane;
-        if (e < n) {
-          const int c = e / F, f = e - c * F;
-          dx[(((long)b * C + c) * T + t) * F + f] = rs * (g[i] - s1 - xh[i] * s2);
-        }
-      }
+      for (int i = 0; i < LNCF_MAXV; ++i)
+        if (i * 64 + lane < n) dx[rowbase + off[i]] = rs * (g[i] - s1 - xh[i] * s2);
     }
   }
 #pragma unroll

@@ -303,46 +303,52 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void upcat_fwd4_kernel(const float* __restrict__ x1, const float* __restrict__ skip,
                                                          float* __restrict__ out, int B, int C1, int H1, int W1, int Cs,
                                                          int Hs, int Ws) {
+  // blockIdx.y = sample, so that the index arithmetic inside a sample is 32-bit (three 64-bit divisions per thread made
+  // this kernel instruction-bound)
   const int Ct = Cs + C1, WQ = Ws >> 2;
-  const long total = (long)B * Ct * Hs * WQ;
+  const unsigned per_sample = (unsigned)Ct * Hs * WQ;
   const int UH = 2 * H1, UW = 2 * W1;
   const int padT = (Hs - UH) / 2, padL = (Ws - UW) / 2;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long r = i / WQ;
+  const int b = blockIdx.y;
+  out += (long)b * Ct * Hs * Ws;
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < per_sample; i += gridDim.x * 256) {
+    const unsigned r = i / (unsigned)WQ;              // row (c, y) inside the sample
     const int x = (int)(i - r * WQ) * 4;
-    const long bc = r / Hs;
-    const int y = (int)(r - bc * Hs);
-    const int b = (int)(bc / Ct);
-    const int c = (int)(bc - (long)b * Ct);
+    const int c = (int)(r / (unsigned)Hs);
+    const int y = (int)(r - (unsigned)c * Hs);
     float4 v = float4{0.f, 0.f, 0.f, 0.f};
     if (c < Cs) {
       v = *reinterpret_cast<const float4*>(skip + (((long)b * Cs + c) * Hs + y) * Ws + x);
     } else {
+      // all sixteen source values are loaded unconditionally from clamped positions and masked afterwards: a guarded
+      // load per tap is a branch and a wait per tap
       const int uy = y - padT;
-      if (uy >= 0 && uy < UH) {
-        int y0, y1;
-        float ly;
-        bilin_src(uy, H1, UH, y0, y1, ly);
-        const float hy = 1.f - ly;
-        const float* p0 = x1 + (((long)b * C1 + (c - Cs)) * H1 + y0) * W1;
-        const float* p1 = x1 + (((long)b * C1 + (c - Cs)) * H1 + y1) * W1;
-        float o[4];
+      const bool yin = uy >= 0 && uy < UH;
+      int y0, y1;
+      float ly;
+      bilin_src(min(max(uy, 0), UH - 1), H1, UH, y0, y1, ly);
+      const float hy = 1.f - ly;
+      const float* p0 = x1 + (((long)b * C1 + (c - Cs)) * H1 + y0) * W1;
+      const float* p1 = x1 + (((long)b * C1 + (c - Cs)) * H1 + y1) * W1;
+      float a00[4], a01[4], a10[4], a11[4], lxs[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int ux = x + u - padL;
-          o[u] = 0.f;
-          if (ux >= 0 && ux < UW) {
-            int x0, x1i;
-            float lx;
-            bilin_src(ux, W1, UW, x0, x1i, lx);
-            const float hx = 1.f - lx;
-            o[u] = hy * (hx * p0[x0] + lx * p0[x1i]) + ly * (hx * p1[x0] + lx * p1[x1i]);
-          }
-        }
-        v = float4{o[0], o[1], o[2], o[3]};
+      for (int u = 0; u < 4; ++u) {
+        const int ux = x + u - padL;
+        int x0, x1i;
+        bilin_src(min(max(ux, 0), UW - 1), W1, UW, x0, x1i, lxs[u]);
+        a00[u] = p0[x0]; a01[u] = p0[x1i]; a10[u] = p1[x0]; a11[u] = p1[x1i];
       }
+      float o[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ux = x + u - padL;
+        const float lx = lxs[u], hx = 1.f - lx;
+        const float t = hy * (hx * a00[u] + lx * a01[u]) + ly * (hx * a10[u] + lx * a11[u]);
+        o[u] = (yin && ux >= 0 && ux < UW) ? t : 0.f;
+      }
+      v = float4{o[0], o[1], o[2], o[3]};
     }
-    *reinterpret_cast<float4*>(out + r * Ws + x) = v;
+    *reinterpret_cast<float4*>(out + (long)r * Ws + x) = v;
   }
 }
 
@@ -636,10 +642,11 @@ int mpa_maxpool2d_bwd(const float* dy, const int32_t* idx, float* dx, int B, int
 int mpa_upcat_fwd(const float* x1, const float* skip, float* out, int B, int C1, int H1, int W1, int Cs, int Hs, int Ws,
                   void* stream) {
   if (!x1 || !skip || !out || Hs < 2 * H1 || Ws < 2 * W1) return MPA_ERR_ARG;
-  if (Ws % 4 == 0 && (((uintptr_t)skip | (uintptr_t)out) & 15) == 0) {
-    const long quads = (long)B * (Cs + C1) * Hs * (Ws / 4);
-    MPA_LAUNCH(upcat_fwd4_kernel, dim3(blocks_for(quads)), dim3(256), 0, (hipStream_t)stream, x1, skip, out, B, C1, H1, W1,
-               Cs, Hs, Ws);
+  if (Ws % 4 == 0 && (((uintptr_t)skip | (uintptr_t)out) & 15) == 0 && B <= 65535 &&
+      (long)(Cs + C1) * Hs * (Ws / 4) < (1L << 31)) {
+    const long per_sample = (long)(Cs + C1) * Hs * (Ws / 4);
+    const dim3 grid((unsigned)std::max<long>(1, std::min<long>(mpa_cdiv(per_sample, 256), 4096)), (unsigned)B);
+    MPA_LAUNCH(upcat_fwd4_kernel, grid, dim3(256), 0, (hipStream_t)stream, x1, skip, out, B, C1, H1, W1, Cs, Hs, Ws);
     return mpa_launch_status();
   }
   const long planes = (long)B * (Cs + C1);
