@@ -100,29 +100,41 @@ __global__ __launch_bounds__(256) void poolrows_drop_add_fwd_kernel(const float*
     const long pl = pb / nblk;
     const int r0 = (int)(pb - pl * nblk) * R;
     const long base = pl * H * W + col;
-    float v[R + KH - 1][V];
+    // All loads first and unconditional: rows outside the plane read a clamped row and are never looked at.  (A guarded
+    // load per row compiles to a branch and a wait per row, i.e. R + KH - 1 serial trips to memory per item.)
+    float v[R + KH - 1][V], rv[R][V];
 #pragma unroll
     for (int j = 0; j < R + KH - 1; ++j) {
-      const int row = r0 - PAD + j;
-      if (row >= 0 && row < H) {
-        if constexpr (V == 4) {
-          const float4 t = *reinterpret_cast<const float4*>(h + base + (long)row * W);
-          v[j][0] = t.x; v[j][1] = t.y; v[j][2] = t.z; v[j][3] = t.w;
-        } else if constexpr (V == 2) {
-          const float2 t = *reinterpret_cast<const float2*>(h + base + (long)row * W);
-          v[j][0] = t.x; v[j][1] = t.y;
-        } else {
-          v[j][0] = h[base + (long)row * W];
-        }
+      const int row = min(max(r0 - PAD + j, 0), H - 1);
+      if constexpr (V == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(h + base + (long)row * W);
+        v[j][0] = t.x; v[j][1] = t.y; v[j][2] = t.z; v[j][3] = t.w;
+      } else if constexpr (V == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(h + base + (long)row * W);
+        v[j][0] = t.x; v[j][1] = t.y;
       } else {
+        v[j][0] = h[base + (long)row * W];
+      }
+    }
+    if (res) {
 #pragma unroll
-        for (int c = 0; c < V; ++c) v[j][c] = 0.f;      // never looked at
+      for (int r = 0; r < R; ++r) {
+        const int row = min(r0 + r, H - 1);
+        if constexpr (V == 4) {
+          const float4 t = *reinterpret_cast<const float4*>(res + base + (long)row * W);
+          rv[r][0] = t.x; rv[r][1] = t.y; rv[r][2] = t.z; rv[r][3] = t.w;
+        } else if constexpr (V == 2) {
+          const float2 t = *reinterpret_cast<const float2*>(res + base + (long)row * W);
+          rv[r][0] = t.x; rv[r][1] = t.y;
+        } else {
+          rv[r][0] = res[base + (long)row * W];
+        }
       }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int row = r0 + r;
-      if (row >= H) break;
+      if (row >= H) continue;
       const long e = base + (long)row * W;
       float o[V];
       int8_t wsel[V];
@@ -139,7 +151,7 @@ __global__ __launch_bounds__(256) void poolrows_drop_add_fwd_kernel(const float*
         }
         float y = best;
         if (drop) y = rng_uniform(seed, offset + (uint64_t)(e + c)) >= p ? best * scale : 0.f;
-        o[c] = res ? y + res[e + c] : y;
+        o[c] = res ? y + rv[r][c] : y;
         wsel[c] = (int8_t)sel;
       }
       if constexpr (V == 4) {
@@ -177,36 +189,40 @@ __global__ __launch_bounds__(256) void poolrows_drop_bwd_kernel(const float* __r
     float g[R + KH - 1][V];
     int8_t w[R + KH - 1][V];
 #pragma unroll
+    for (int j = 0; j < R + KH - 1; ++j) {      // all loads first, unconditional (clamped rows are masked below)
+      const int row = min(max(r0 - PAD + j, 0), H - 1);
+      const long e = base + (long)row * W;
+      if constexpr (V == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(dout + e);
+        const char4 s = *reinterpret_cast<const char4*>(which + e);
+        g[j][0] = t.x; g[j][1] = t.y; g[j][2] = t.z; g[j][3] = t.w;
+        w[j][0] = s.x; w[j][1] = s.y; w[j][2] = s.z; w[j][3] = s.w;
+      } else if constexpr (V == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(dout + e);
+        const char2 s = *reinterpret_cast<const char2*>(which + e);
+        g[j][0] = t.x; g[j][1] = t.y;
+        w[j][0] = s.x; w[j][1] = s.y;
+      } else {
+        g[j][0] = dout[e]; w[j][0] = which[e];
+      }
+    }
+#pragma unroll
     for (int j = 0; j < R + KH - 1; ++j) {
       const int row = r0 - PAD + j;      // window (= output) row
-      if (row >= 0 && row < H) {
-        const long e = base + (long)row * W;
-        if constexpr (V == 4) {
-          const float4 t = *reinterpret_cast<const float4*>(dout + e);
-          const char4 s = *reinterpret_cast<const char4*>(which + e);
-          g[j][0] = t.x; g[j][1] = t.y; g[j][2] = t.z; g[j][3] = t.w;
-          w[j][0] = s.x; w[j][1] = s.y; w[j][2] = s.z; w[j][3] = s.w;
-        } else if constexpr (V == 2) {
-          const float2 t = *reinterpret_cast<const float2*>(dout + e);
-          const char2 s = *reinterpret_cast<const char2*>(which + e);
-          g[j][0] = t.x; g[j][1] = t.y;
-          w[j][0] = s.x; w[j][1] = s.y;
-        } else {
-          g[j][0] = dout[e]; w[j][0] = which[e];
-        }
-        if (drop) {
+      const bool on = row >= 0 && row < H;
+      const long e = base + (long)row * W;
 #pragma unroll
-          for (int c = 0; c < V; ++c) g[j][c] = rng_uniform(seed, offset + (uint64_t)(e + c)) >= p ? g[j][c] * scale : 0.f;
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < V; ++c) { g[j][c] = 0.f; w[j][c] = -1; }
+      for (int c = 0; c < V; ++c) {
+        float t = on ? g[j][c] : 0.f;
+        if (drop) t = rng_uniform(seed, offset + (uint64_t)(e + c)) >= p ? t * scale : 0.f;
+        g[j][c] = t;
+        w[j][c] = on ? w[j][c] : (int8_t)-1;
       }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int row = r0 + r;
-      if (row >= H) break;
+      if (row >= H) continue;
       float o[V];
 #pragma unroll
       for (int c = 0; c < V; ++c) {
