@@ -270,15 +270,23 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
   const float* xb = x + (long)b * R * Cc;
   float* yb = y + (long)b * R * Cc;
-  for (int k = ty; k < 32; k += 8) {
-    const int r = r0 + k, c = c0 + tx;
-    float v = 0.f;
-    if (r < R && c < Cc) {
-      v = xb[(long)r * Cc + c];
-      if (pe_mode == 2) v += pe[(long)r * Cc + c];      // pe laid out like the input (R,Cc)
-    }
-    tile[k][tx] = v;
+  // the four loads of a thread are issued together, from clamped positions (a guarded load each is a branch and a
+  // wait each); positions outside the matrix are never written back
+  float v[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int r = min(r0 + ty + 8 * u, R - 1), c = min(c0 + tx, Cc - 1);
+    v[u] = xb[(long)r * Cc + c];
   }
+  if (pe_mode == 2) {                                    // pe laid out like the input (R,Cc)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = min(r0 + ty + 8 * u, R - 1), c = min(c0 + tx, Cc - 1);
+      v[u] += pe[(long)r * Cc + c];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) tile[ty + 8 * u][tx] = v[u];
   __syncthreads();
   for (int k = ty; k < 32; k += 8) {
     const int c = c0 + k, r = r0 + tx;

@@ -537,24 +537,33 @@ __global__ __launch_bounds__(256) void upcat_bwd_sep_kernel(const float* __restr
     const int b = (int)(bc / C1);
     const int c = (int)(bc - (long)b * C1);
     const float* dp = dout + (((long)b * Ct + Cs + c) * Hs) * Ws;
+    // the six candidate rows as fixed slots (weight 0 and a clamped row where a slot does not contribute): the loads of
+    // a lane are then unconditional and issued together instead of one trip to memory per contributing row
     float wys[6];
     int oys[6];
-    int nwy = 0;
-    const int uy_lo = max(0, 2 * ii - 2), uy_hi = min(UH - 1, 2 * ii + 3);
-    for (int uy = uy_lo; uy <= uy_hi; ++uy) {
-      int y0, y1;
-      float ly;
-      bilin_src(uy, H1, UH, y0, y1, ly);
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int uy = 2 * ii - 2 + u;
       float wy = 0.f;
-      if (y0 == ii) wy += 1.f - ly;
-      if (y1 == ii) wy += ly;
-      const int oy = uy + padT;
-      if (wy == 0.f || oy < 0 || oy >= Hs) continue;
-      wys[nwy] = wy; oys[nwy] = oy; ++nwy;
+      int oy = 0;
+      if (uy >= 0 && uy < UH) {
+        int y0, y1;
+        float ly;
+        bilin_src(uy, H1, UH, y0, y1, ly);
+        if (y0 == ii) wy += 1.f - ly;
+        if (y1 == ii) wy += ly;
+        oy = uy + padT;
+        if (oy < 0 || oy >= Hs) { wy = 0.f; oy = 0; }
+      }
+      wys[u] = wy; oys[u] = wy != 0.f ? oy : min(max(2 * ii + padT, 0), Hs - 1);
     }
     for (int x = lane; x < Ws; x += 64) {
+      float d[6];
+#pragma unroll
+      for (int u = 0; u < 6; ++u) d[u] = dp[oys[u] * Ws + x];
       float a = 0.f;
-      for (int tt = 0; tt < nwy; ++tt) a += wys[tt] * dp[oys[tt] * Ws + x];
+#pragma unroll
+      for (int u = 0; u < 6; ++u) a += wys[u] != 0.f ? wys[u] * d[u] : 0.f;
       t[x] = a;
     }
     __builtin_amdgcn_wave_barrier();
