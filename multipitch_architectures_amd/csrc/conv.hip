@@ -150,10 +150,19 @@ FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
             const int nChunks = (int)mpa_cdiv(Cin, CK);
             int KS = 1;
             static const int ks_max = getenv("MPA_FWD_KS_MAX") ? atoi(getenv("MPA_FWD_KS_MAX")) : 16;   // diagnostics
+            static const int ks_force = getenv("MPA_FWD_KS_FORCE") ? atoi(getenv("MPA_FWD_KS_FORCE")) : 0;   // diagnostics
+            if (ks_force > 1 && allow_split && ks_force <= nChunks) KS = ks_force;
+            else
             if (xcu <= 2.0 * bpc && allow_split) {
+              // Each extra slice pays a prologue / epilogue: ~6 % of a full-K workgroup for the short reductions of the
+              // deep levels, next to nothing for 32 chunks of 15x15 taps.  Slices of a grid that is a bad fraction of
+              // the chip level it out: 704 tiles are 2.75 per CU (the busiest CU works through 3), 4 x 704 quarter
+              // tiles are exactly 11 per CU -- measured 3.97 -> 3.61 ms for the 128->16 backward-data at local batch
+              // 32 (scratch/ks_force.sh), i.e. whole quarter tiles and no drifting tail up to ~6 resident sets.
+              const double slice_cost = std::min(0.06, 60.0 / ((double)nChunks * kh * kw * (CK / 4)));
               for (int ks = 2; ks <= ks_max && ks <= nChunks; ks *= 2) {
-                const double c2 = cu_load(xcu * ks) * per_block * (1.0 / ks + 0.06) * (1.0 + 0.25 * (1.0 - fill)) +
-                                  1e-3 * blocks * ks;
+                const double load = xcu * ks <= 6.0 * bpc ? std::ceil(xcu * ks) : cu_load(xcu * ks);
+                const double c2 = load * per_block * (1.0 / ks + slice_cost) * (1.0 + 0.25 * (1.0 - fill)) + 1e-3 * blocks * ks;
                 if (c2 < cost) { cost = c2; KS = ks; }
               }
             }
