@@ -2033,6 +2033,31 @@ Wg15Plan plan_wgrad15(const mpa_conv_desc* d) {
   long S = std::max<long>(1, (2 * slots) / groups);
   if (S > totalTiles) S = totalTiles;
   if (S > 1024) S = 1024;
+  // With few tiles per slice the rounding decides: 192 tiles over 128 slices are 2 tiles for half of the workgroups and
+  // 1 for the others (measured 107 instead of 125 TFLOP/s for the 32->16 layer at local batch 32).  Among slice counts
+  // from half to twice the target, take the cheapest by a small model calibrated on scratch/wg15_s.sh: the busiest CU
+  // works through ceil(workgroups / 256) workgroups of ceil(tiles / S) tiles (a tile = its MFMA cycles + 10 % staging;
+  // + 8 % when a CU holds a single workgroup and nothing overlaps its staging), and every slice costs one write and one
+  // read of its partial sums in the reduction (0.9 us for 128 couts x 16 channels, which is why the large layers want
+  // few slices and the 16-cout layers many).
+  if (totalTiles / S < 8 && !getenv("MPA_WG15_S_OLD")) {
+    const long lo = std::max<long>(1, S / 2), hi = std::min<long>(std::min<long>(2 * S, totalTiles), 1024);
+    const double t_tile = 1.1 * (double)pl.TH * (pl.TW / 4) * pl.NBC * 15 * 32.0 / 2.4e9;
+    const double t_slice = (double)d->Cout * (d->Cin * 225 + 1) * 8.0 / 4.0e12;
+    double best = 1e300;
+    long bestS = S;
+    for (long c = lo; c <= hi; ++c) {
+      const long per_cu_wgs = mpa_cdiv(c * groups, 256);
+      const double est = (double)per_cu_wgs * (double)mpa_cdiv(totalTiles, c) * t_tile * (per_cu_wgs < 2 ? 1.08 : 1.0) +
+                         (double)c * t_slice;
+      if (est < best) { best = est; bestS = c; }
+    }
+    S = bestS;
+  }
+  if (const char* e = getenv("MPA_WG15_S")) {      // diagnostics: force the slice count
+    const long f = atol(e);
+    if (f >= 1 && f <= std::min<long>(totalTiles, 1024)) S = f;
+  }
   pl.S = (int)S;
   return pl;
 }
