@@ -53,6 +53,14 @@ typedef struct mpa_conv_desc {
 int64_t mpa_conv2d_packed_floats(const mpa_conv_desc* d, int mode);
 /* repack (Cout,Cin,kh,kw) filters for fwd (mode 0) or, flipped+transposed, for bwd-data (mode 1) */
 int mpa_conv2d_pack(const mpa_conv_desc* d, int mode, const float* w, float* w_packed, void* stream);
+/* All filter banks of a model in one launch (the training step re-packs every bank after each optimizer step).
+ * mpa_conv2d_pack_entry fills one table entry (mpa_conv2d_pack_entry_bytes() bytes of host memory) for what
+ * mpa_conv2d_pack(d, mode, w, w_packed) would do; the caller copies the entries, back to back, into device memory once
+ * and mpa_conv2d_pack_many(device_table, n) re-packs all of them (w and w_packed are read from the entries: they must
+ * stay where they were). */
+int mpa_conv2d_pack_entry_bytes(void);
+int mpa_conv2d_pack_entry(const mpa_conv_desc* d, int mode, const float* w, float* w_packed, void* host_entry);
+int mpa_conv2d_pack_many(const void* device_table, int n, void* stream);
 /* y = act(conv(x, w) + bias) ; bias may be NULL */
 int mpa_conv2d_fwd(const mpa_conv_desc* d, const float* x, const float* w_packed, const float* bias,
                    float* y, int act, float slope, void* stream);

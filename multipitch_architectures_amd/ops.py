@@ -111,10 +111,87 @@ def _packed(weight, desc, mode):
         n = lib.mpa_conv2d_packed_floats(ctypes.byref(desc), mode)
         if n < 0:
             L.check(int(n), "mpa_conv2d_packed_floats")
-        buf = torch.empty(int(n), dtype=torch.float32, device=weight.device)
+        # a bank that was packed for an earlier state of this weight is re-used (same size, same place): the table of
+        # pack tables (run_pack_table) point at it
+        buf = _pack_buffers.get((id(weight), key))
+        if buf is None or buf[0]() is not weight or buf[1].numel() != int(n):
+            if buf is not None:
+                _pack_keepalive.append(buf[1])
+            buf = (weakref.ref(weight), torch.empty(int(n), dtype=torch.float32, device=weight.device),
+                   ctypes.string_at(ctypes.byref(desc), ctypes.sizeof(desc)), mode)
+            _pack_buffers[(id(weight), key)] = buf
+        buf = buf[1]
         _chk(lib.mpa_conv2d_pack(ctypes.byref(desc), mode, _p(weight), _p(buf), _s()), "mpa_conv2d_pack")
         ent[2][key] = buf
+    _pack_used.add((id(weight), key))
     return buf
+
+
+_pack_buffers = {}      # (id(weight), key) -> (weakref(weight), packed buffer, raw conv desc, mode): stable storage
+_pack_used = set()      # banks asked for since begin_pack_window()
+
+
+class PackTable:
+    """device table of filter banks (entries of mpa_conv2d_pack_entry): one launch re-packs all of them"""
+
+    def __init__(self, keys, device, n):
+        self.keys, self.device, self.n = keys, device, n
+
+
+_pack_keepalive = []      # replaced banks: a captured graph may still launch on them
+
+
+def begin_pack_window():
+    """forget which banks were used so far: pack_window_keys() then names exactly the banks used from here on (a training
+    step calls this first, so that evaluation passes between steps do not leak their shapes into the step's table)"""
+    global _pack_used
+    _pack_used = set()
+
+
+def pack_window_keys():
+    return tuple(sorted(k for k in _pack_used if k in _pack_buffers and _pack_buffers[k][0]() is not None))
+
+
+def build_pack_table(keys):
+    """table for run_pack_table(): the banks `keys` (from pack_window_keys()) with their weights and geometries.  Copies
+    a few KB to the device -- not inside a graph capture."""
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("the set of filter banks changed inside a graph capture: run one eager step first")
+    if not keys:
+        return PackTable((), None, 0)
+    lib = _lib()
+    esz = lib.mpa_conv2d_pack_entry_bytes()
+    host = ctypes.create_string_buffer(esz * len(keys))
+    dev = None
+    for i, k in enumerate(keys):
+        wref, buf, raw, mode = _pack_buffers[k]
+        w = wref()
+        desc = L.ConvDesc.from_buffer_copy(raw)
+        _chk(lib.mpa_conv2d_pack_entry(ctypes.byref(desc), mode, _p(w), _p(buf), ctypes.byref(host, i * esz)),
+             "mpa_conv2d_pack_entry")
+        dev = w.device
+    return PackTable(keys, torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(dev), len(keys))
+
+
+def run_pack_table(tab):
+    """Re-pack, in one launch, every filter bank of the table for the weights as they are now (a training step does this
+    first: its forward / backward then finds every bank current instead of re-packing 2 banks per convolution lazily,
+    44 small launches for SAUnet:L).  Banks of the same weights that are not in the table (other batch sizes, evaluation
+    shapes) are dropped from the cache and re-packed lazily when they are needed again."""
+    if tab.n == 0:
+        return
+    for wid, key in tab.keys:
+        ent = _pack_buffers.get((wid, key))
+        if ent is None or ent[0]() is None:
+            raise RuntimeError("a weight of this pack table no longer exists")
+    _chk(_lib().mpa_conv2d_pack_many(_p(tab.device), tab.n, _s()), "mpa_conv2d_pack_many")
+    per_weight = {}
+    for wid, key in tab.keys:
+        per_weight.setdefault(wid, []).append(key)
+    for wid, keys in per_weight.items():
+        w = _pack_buffers[(wid, keys[0])][0]()
+        sig = (w.data_ptr(), w._version, _param_epoch)
+        _pack_cache[wid] = (weakref.ref(w), sig, {k: _pack_buffers[(wid, k)][1] for k in keys})
 
 
 # optional HIP-event probe around one class of conv launches (bench.py's live roofline measurement)

@@ -16,6 +16,8 @@ running statistics), so one capture serves the whole run.
 
 Batches whose shape differs from the captured one (the last, smaller batch of an epoch) run eagerly.
 """
+import os
+
 import torch
 
 from . import ops
@@ -31,15 +33,30 @@ class TrainStep:
         self._eager_shape = None     # shapes of the last eager step (the capture follows an eager step of its shape)
         self._x = self._y = self._loss = None
         self.replays = 0
+        self._pack_tables = {}       # (x shape, y shape) -> ops.PackTable of the filter banks that shape's step uses
+        self._old_tables = []
+        self._use_pack_tables = os.environ.get("MPA_PACK_TABLES", "1") != "0"      # diagnostics: "0" = pack bank by bank
 
     # the loop body, launched kernel by kernel
     def eager(self, x, y):
+        # every filter bank this shape's step uses, re-packed for the current weights in one launch (the table is known
+        # from the previous step of the shape; the first one packs lazily, bank by bank)
+        shape = (tuple(x.shape), tuple(y.shape))
+        tab = self._pack_tables.get(shape) if self._use_pack_tables else None
+        if tab is not None:
+            ops.run_pack_table(tab)
+        ops.begin_pack_window()
         loss = self.criterion(self.model(x), y)
         self.opt.zero_grad()
         loss.backward()
         if self.averager is not None:
             self.averager.finish()
         self.opt.step()
+        keys = ops.pack_window_keys() if self._use_pack_tables else None
+        if self._use_pack_tables and (tab is None or tab.keys != keys):
+            if tab is not None:
+                self._old_tables.append(tab)         # a captured graph may still launch on it
+            self._pack_tables[shape] = ops.build_pack_table(keys)
         ops.rng_advance()
         # detached: a caller holding the loss across iterations (every training loop does) must not keep this step's
         # autograd nodes alive -- stale AccumulateGrad nodes would run on the stream they were created on and break the

@@ -137,3 +137,40 @@ def test_eager_forward_after_replays_sees_the_updated_weights(dev):
         ref = oracle_forward("tiny:Unet", sd, x, train=False)
     assert float((got - ref).abs().max()) <= 1e-4
     model.train()
+
+
+def test_evaluation_passes_between_steps_do_not_disturb_the_step_or_see_stale_filters(dev):
+    """the step re-packs all its filter banks in one launch at its start (`ops.run_pack_table`); evaluation
+    forwards of other shapes between the steps -- also between the first eager step and the capture -- must neither leak
+    their banks into the step's table nor read banks packed for older weights"""
+    from helpers import oracle_forward
+    cfg = CONFIGS["tiny:CNN"]      # (dropout, no BatchNorm: loss sequences are comparable to 2e-5)
+
+    def run(use_graph, with_eval):
+        model = getattr(nn_models, cfg["cls"])(**cfg["kwargs"])
+        model.load_state_dict(det_fill(model.state_dict()))
+        model.to(dev).train()
+        ops.manual_seed(5)
+        opt = AdamW(model.parameters(), lr=1e-3)
+        ts = TrainStep(model, BCELoss(), opt, use_graph=use_graph)
+        xe, _ = synth_batch(3, 90, seed=9)
+        losses, evals = [], []
+        for i in range(5):
+            x, y = synth_batch(4, 75, seed=100 + (i % 2))
+            losses.append(float(ts(x.to(dev), y.to(dev))))
+            if with_eval:
+                model.eval()
+                with torch.no_grad():
+                    evals.append(model(xe.to(dev)).cpu())
+                model.train()
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        return losses, evals, sd, xe, ts
+
+    l_ref, _, _, _, _ = run(False, False)
+    l_g, ev, sd, xe, ts = run(True, True)
+    assert ts.replays == 4
+    np.testing.assert_allclose(l_g, l_ref, rtol=2e-5)
+    # the last evaluation pass used the weights of step 5, not banks packed for an earlier step
+    ref = oracle_forward("tiny:CNN", sd, xe, train=False)
+    assert (ev[-1] - ref).abs().max() < 1e-4
+    assert (ev[0] - ev[-1]).abs().max() > 1e-6          # ... and the weights did move
