@@ -1109,6 +1109,27 @@ WgPlan plan_wgrad(const mpa_conv_desc* d) {
   if (groups * S < slots && S < totalTiles) S = mpa_cdiv(slots, groups);
   if (S > totalTiles) S = totalTiles;
   if (S > 1024) S = 1024;
+  // few tiles per slice: pick the slice count by the same small model as plan_wgrad15 (the busiest CU's workgroups x
+  // tiles per slice x tile time, + 8 % when a CU holds a single workgroup, + one write and read of the partial sums
+  // per slice) -- 160 tiles over 93 slices are 2 tiles for most workgroups and 1 for the rest
+  if (totalTiles / S < 8 && !getenv("MPA_WG_S_OLD")) {
+    const long lo = std::max<long>(1, S / 2), hi = std::min<long>(std::min<long>(2 * S, totalTiles), 1024);
+    const double t_tile = 1.1 * (double)best.TH * (best.DP / 4) * best.NBC * best.NTW * 32.0 / 2.4e9;
+    const double t_slice = (double)std::min(d->Cout, best.COT * best.coTiles) * (best.Ntot + 1) * 8.0 / 4.0e12;
+    double bestc = 1e300;
+    long bestS = S;
+    for (long c = lo; c <= hi; ++c) {
+      const long per_cu_wgs = mpa_cdiv(c * groups, 256);
+      const double est = (double)per_cu_wgs * (double)mpa_cdiv(totalTiles, c) * t_tile * (per_cu_wgs < 2 ? 1.08 : 1.0) +
+                         (double)c * t_slice;
+      if (est < bestc) { bestc = est; bestS = c; }
+    }
+    S = bestS;
+  }
+  if (const char* e = getenv("MPA_WG_S")) {      // diagnostics: force the slice count
+    const long f = atol(e);
+    if (f >= 1 && f <= std::min<long>(totalTiles, 1024)) S = f;
+  }
   best.S = (int)S;
   return best;
 }
