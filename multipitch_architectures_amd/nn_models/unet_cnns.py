@@ -23,7 +23,8 @@ class _DoubleConvSeq(nn.Sequential):
         i = 0
         while i < len(mods):
             conv, bn = mods[i], mods[i + 1]
-            if bn.training:
+            if bn.training and not (conv._forward_hooks or conv._forward_pre_hooks):
+                # (a hooked convolution goes through nn.Module.__call__, as in the reference's nn.Sequential)
                 y, partials = conv.forward_stats(h)
                 h = bn(y, relu=True, partials=partials)
             else:

@@ -134,8 +134,19 @@ _pack_used = set()      # banks asked for since begin_pack_window()
 class PackTable:
     """device table of filter banks (entries of mpa_conv2d_pack_entry): one launch re-packs all of them"""
 
-    def __init__(self, keys, device, n):
+    def __init__(self, keys, device, n, wptrs=()):
         self.keys, self.device, self.n = keys, device, n
+        self.wptrs = wptrs          # data_ptr() of each key's weight when the table was built (baked into the entries)
+
+
+def pack_table_valid(tab):
+    """every weight of the table is alive and still at the address the table's entries carry"""
+    for (wid, key), ptr in zip(tab.keys, tab.wptrs):
+        ent = _pack_buffers.get((wid, key))
+        w = ent[0]() if ent is not None else None
+        if w is None or w.data_ptr() != ptr:
+            return False
+    return True
 
 
 _pack_keepalive = []      # replaced banks: a captured graph may still launch on them
@@ -159,6 +170,8 @@ def build_pack_table(keys):
         raise RuntimeError("the set of filter banks changed inside a graph capture: run one eager step first")
     if not keys:
         return PackTable((), None, 0)
+    for k in [k for k, v in _pack_buffers.items() if v[0]() is None]:      # banks of weights that no longer exist
+        del _pack_buffers[k]
     lib = _lib()
     esz = lib.mpa_conv2d_pack_entry_bytes()
     host = ctypes.create_string_buffer(esz * len(keys))
@@ -170,7 +183,8 @@ def build_pack_table(keys):
         _chk(lib.mpa_conv2d_pack_entry(ctypes.byref(desc), mode, _p(w), _p(buf), ctypes.byref(host, i * esz)),
              "mpa_conv2d_pack_entry")
         dev = w.device
-    return PackTable(keys, torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(dev), len(keys))
+    return PackTable(keys, torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(dev), len(keys),
+                     tuple(_pack_buffers[k][0]().data_ptr() for k in keys))
 
 
 def run_pack_table(tab):
@@ -180,10 +194,8 @@ def run_pack_table(tab):
     shapes) are dropped from the cache and re-packed lazily when they are needed again."""
     if tab.n == 0:
         return
-    for wid, key in tab.keys:
-        ent = _pack_buffers.get((wid, key))
-        if ent is None or ent[0]() is None:
-            raise RuntimeError("a weight of this pack table no longer exists")
+    if not pack_table_valid(tab):
+        raise RuntimeError("a weight of this pack table no longer exists or has moved: build a new table")
     _chk(_lib().mpa_conv2d_pack_many(_p(tab.device), tab.n, _s()), "mpa_conv2d_pack_many")
     per_weight = {}
     for wid, key in tab.keys:

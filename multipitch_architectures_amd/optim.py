@@ -24,6 +24,32 @@ class AdamW(torch.optim.Optimizer):
             raise ValueError("invalid AdamW hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False))
         self._tables = {}
+        self.table_epoch = 0       # bumped whenever the device tables are dropped: a captured graph of an older epoch is stale
+
+    def _drop_tables(self):
+        """forget the device-side pointer tables / step count: they are rebuilt from ``self.state`` at the next step"""
+        if getattr(self, "_tables", None):
+            self._tables = {}
+        self.table_epoch = getattr(self, "table_epoch", 0) + 1
+
+    def load_state_dict(self, state_dict):
+        """as torch.optim.Optimizer.load_state_dict; the step count, learning rate and exp_avg / exp_avg_sq pointers the
+        update kernel reads live in device tables seeded from ``self.state`` -- they are rebuilt from the loaded state
+        (a graph captured before the load is discarded by ``step.TrainStep``)"""
+        super().load_state_dict(state_dict)
+        self._drop_tables()
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        self._drop_tables()
+
+    def invalidate_grad_table(self):
+        """A replayed graph re-runs its captured ``mpa_store_ptrs`` and leaves the *graph's* gradient addresses in the
+        device table: the host-side cache of what the table holds is stale after every replay (an eager step that
+        follows one -- the odd last batch of an epoch -- must upload its own gradient pointers even when the caching
+        allocator hands out the same addresses as in the previous eager step)."""
+        for tab in self._tables.values():
+            tab["gkey"] = None
 
     def _table(self, gi, plist):
         key = (gi, tuple(p.data_ptr() for p in plist))

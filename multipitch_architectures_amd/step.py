@@ -34,7 +34,9 @@ class TrainStep:
         self._x = self._y = self._loss = None
         self.replays = 0
         self._pack_tables = {}       # (x shape, y shape) -> ops.PackTable of the filter banks that shape's step uses
-        self._old_tables = []
+        self._old_tables = []        # tables a live graph may still launch on (cleared when the graph is dropped)
+        self._opt_epoch = None       # optimizer.table_epoch the graph was captured under
+        self._no_graph_shapes = set()   # shapes whose capture failed: they keep running kernel by kernel
         self._use_pack_tables = os.environ.get("MPA_PACK_TABLES", "1") != "0"      # diagnostics: "0" = pack bank by bank
 
     # the loop body, launched kernel by kernel
@@ -43,6 +45,11 @@ class TrainStep:
         # from the previous step of the shape; the first one packs lazily, bank by bank)
         shape = (tuple(x.shape), tuple(y.shape))
         tab = self._pack_tables.get(shape) if self._use_pack_tables else None
+        if tab is not None and not ops.pack_table_valid(tab):
+            # a weight was re-allocated (model.to(), load_state_dict(assign=True), p.data = ...): the table's baked-in
+            # addresses are stale -- pack lazily this step and build a new table at its end
+            self._pack_tables.pop(shape)
+            tab = None
         if tab is not None:
             ops.run_pack_table(tab)
         ops.begin_pack_window()
@@ -71,19 +78,50 @@ class TrainStep:
         self.opt.sync_hyper()
         self.opt.zero_grad(set_to_none=True)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            self._loss = self.eager(self._x, self._y)
+        rng_local = ops._Rng.local
+        try:
+            with torch.cuda.graph(graph):
+                self._loss = self.eager(self._x, self._y)
+        except Exception:
+            # nothing of the failed capture ran on the device; restore the host-side bookkeeping it touched and let the
+            # caller run this shape kernel by kernel from now on
+            ops._Rng.local = rng_local
+            self._x = self._y = self._loss = None
+            self.graph = self.shape = None
+            self.opt.zero_grad(set_to_none=True)
+            self.opt.invalidate_grad_table()
+            raise
         self.graph, self.shape = graph, (tuple(x.shape), tuple(y.shape))
+        self._opt_epoch = getattr(self.opt, "table_epoch", None)
+
+    def _drop_graph(self):
+        self.graph = self.shape = None
+        self._x = self._y = self._loss = None
+        self._eager_shape = None
+        self._old_tables.clear()
 
     def __call__(self, x, y):
-        if not self.use_graph:
+        if not self.use_graph or not self.model.training:
+            # the captured graph is the *training* step (dropout, batch statistics, running-stat updates): after
+            # model.eval() the loop body runs kernel by kernel with whatever mode the modules are in
             return self.eager(x, y)
         shape = (tuple(x.shape), tuple(y.shape))
+        if self.graph is not None:
+            tab = self._pack_tables.get(self.shape)
+            if self._opt_epoch != getattr(self.opt, "table_epoch", None) or \
+                    (tab is not None and not ops.pack_table_valid(tab)):
+                # optimizer.load_state_dict() / add_param_group(), or re-allocated weights: the graph has the old
+                # exp_avg / step-count / weight addresses baked in -- capture again after one eager step
+                self._drop_graph()
         if self.graph is None:
-            if shape != self._eager_shape or not self.model.training:
+            if shape != self._eager_shape or shape in self._no_graph_shapes:
                 self._eager_shape = shape
                 return self.eager(x, y)
-            self._capture(x, y)
+            try:
+                self._capture(x, y)
+            except RuntimeError:
+                self._no_graph_shapes.add(shape)
+                return self.eager(x, y)
         if shape != self.shape:
             return self.eager(x, y)
         if x.data_ptr() != self._x.data_ptr():
@@ -94,6 +132,7 @@ class TrainStep:
         self.graph.replay()
         self.replays += 1
         self.opt.note_steps(1)                       # host mirrors of what the graph did on the device
+        self.opt.invalidate_grad_table()             # the replay left the graph's gradient addresses in the device table
         ops.bump_param_epoch()
         return self._loss
 

@@ -47,10 +47,16 @@ CASES += [
     ("DRCNN:L", 1, 75, False),
     ("Unet:L", 2, 75, True),
     ("SAUnet:L", 2, 75, True), ("SAUnet:L", 2, 174, False), ("SAUnet:L", 25, 75, False),
-    ("SAUSnet:L", 2, 75, False),
+    ("SAUSnet:L", 2, 75, True),
     ("BLUnet:XXL", 2, 75, True),
-    ("PUnet:XL", 2, 75, False), ("PUnet:M", 2, 75, True),
+    ("PUnet:XL", 2, 75, True), ("PUnet:M", 2, 75, True),
 ]
+# round 3: paper-size train-step goldens for the configurations that only had forward ones (the 70-cout tap-fold
+# backward-weight inside DRCNN:L, PUnet:XL's 256/512-channel levels, SAUSnet:L's second attention stage), and one
+# non-chaotic (BatchNorm over 32 patches) train case per family for the tight whole-model gradient check
+CASES += [("DRCNN:L", 2, 75, True)]
+for _name in ("tiny:CNN", "tiny:DRCNN", "tiny:SAUnet", "tiny:SAUSnet", "tiny:BLUnet", "tiny:PUnet"):
+    CASES += [(_name, 32, 75, True)]
 
 _real_zeros = torch.zeros
 

@@ -236,3 +236,20 @@ def test_bench_spawns_its_own_ranks_and_fails_loudly_without_gpus():
     assert r.returncode != 0
     assert r.stderr.count("needs an MI355X") >= 1 and "stopping the other ranks" in r.stderr
     assert r.stdout.strip() == ""
+
+
+def test_adamw_load_state_dict_and_add_param_group_drop_the_device_tables():
+    """the update kernel reads step count / exp_avg pointers from device tables built lazily from ``opt.state``: loading a
+    state dict (resume) or adding a group must invalidate them and tell ``TrainStep`` that its graph is stale"""
+    import torch
+    from multipitch_architectures_amd.optim import AdamW
+    w = torch.nn.Parameter(torch.zeros(3))
+    opt = AdamW([w], lr=1e-3)
+    e0 = opt.table_epoch
+    opt._tables[0] = {"key": None, "gkey": (1,)}
+    opt.invalidate_grad_table()
+    assert opt._tables[0]["gkey"] is None
+    opt.load_state_dict(opt.state_dict())
+    assert opt._tables == {} and opt.table_epoch == e0 + 1
+    opt.add_param_group({"params": [torch.nn.Parameter(torch.zeros(2))]})
+    assert opt.table_epoch == e0 + 2

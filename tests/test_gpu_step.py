@@ -110,6 +110,80 @@ def test_odd_batch_runs_eagerly_between_replays(dev):
     assert all(st["step"] == 5 for st in opt.state.values())
 
 
+def test_eager_steps_between_replays_use_their_own_gradients(dev):
+    """eager -> replay -> eager: a replay re-runs the captured mpa_store_ptrs and leaves the *graph's* gradient addresses
+    in the optimizer's device table; the odd batch that follows must upload its own pointers even when the caching
+    allocator returns the same p.grad addresses as in the previous odd batch (optim.py:70)"""
+    sizes = [6, 6, 3, 6, 3, 6, 3, 6]
+    le, pe, _, _ = _run(dev, "tiny:CNN", False, len(sizes), batches=sizes)
+    lg, pg, ts, opt = _run(dev, "tiny:CNN", True, len(sizes), batches=sizes)
+    assert ts.replays == 4
+    np.testing.assert_allclose(lg, le, rtol=3e-4)
+    for a, b in zip(pg, pe):
+        assert float((a - b).abs().max()) <= 3e-4 * max(float(b.abs().max()), 1e-3)
+    assert all(st["step"] == len(sizes) for st in opt.state.values())
+
+
+def test_optimizer_load_state_dict_after_steps_reaches_the_kernel_and_drops_the_graph(dev):
+    """resume from a checkpoint after warm-up steps: step count / exp_avg / exp_avg_sq of the loaded state must be what
+    the update kernel uses (they live in device tables), and a graph captured before the load must not be replayed
+    (optim.py:42).  Dropout off, so that two runs are comparable step by step."""
+    cfg = CONFIGS["tiny:CNN"]
+
+    def fresh():
+        model = getattr(nn_models, cfg["cls"])(**cfg["kwargs"])
+        model.load_state_dict(det_fill(model.state_dict()))
+        for m in model.modules():
+            if hasattr(m, "p") and isinstance(getattr(m, "p"), float):
+                m.p = 0.0
+        model.to(dev).train()
+        opt = AdamW(model.parameters(), lr=1e-3)
+        return model, opt, TrainStep(model, BCELoss(), opt)
+
+    def batch(i):
+        x, y = synth_batch(4, 75, seed=100 + (i % 2))
+        return x.to(dev), y.to(dev)
+
+    # run A: 5 steps, checkpoint after step 3
+    model, opt, ts = fresh()
+    for i in range(3):
+        ts(*batch(i))
+    ck_m = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    sd = opt.state_dict()
+    ck_o = {"state": {k: {n: (t.clone() if torch.is_tensor(t) else t) for n, t in st.items()}
+                      for k, st in sd["state"].items()}, "param_groups": sd["param_groups"]}
+    for i in range(3, 5):
+        ts(*batch(i))
+    want = [p.detach().cpu().clone() for p in model.parameters()]
+    # run B: another history (2 steps from the initial weights on other batches, graph captured), then the checkpoint
+    model2, opt2, ts2 = fresh()
+    for i in range(2):
+        ts2(*batch(i + 1))
+    assert ts2.graph is not None
+    model2.load_state_dict(ck_m)
+    opt2.load_state_dict(ck_o)
+    for i in range(3, 5):
+        ts2(*batch(i))
+    assert all(st["step"] == 5 for st in opt2.state.values())
+    got = [p.detach().cpu() for p in model2.parameters()]
+    for a, b in zip(got, want):
+        assert float((a - b).abs().max()) <= 3e-4 * max(float(b.abs().max()), 1e-3)
+
+
+def test_replay_is_refused_after_model_eval(dev):
+    """model.eval() between steps: the train-mode graph (dropout, batch statistics) must not be replayed"""
+    _, _, ts, _ = _run(dev, "tiny:DRCNN", True, 3, B=4)
+    assert ts.graph is not None
+    n = ts.replays
+    ts.model.eval()
+    x, y = synth_batch(4, 75, seed=100)
+    ts(x.to(dev), y.to(dev))
+    assert ts.replays == n
+    ts.model.train()
+    ts(x.to(dev), y.to(dev))
+    assert ts.replays == n + 1
+
+
 @pytest.mark.parametrize("name", ["tiny:SAUnet", "tiny:BLUnet", "tiny:PUnet", "tiny:DRCNN"])
 def test_every_family_captures_and_trains(dev, name):
     """BatchNorm running statistics, batch-axis attention, the BiLSTM recurrence and the two-headed loss inside a graph"""
