@@ -80,6 +80,26 @@ int64_t mpa_conv2d_bwd_weight_workspace(const mpa_conv_desc* d);
 int mpa_conv2d_bwd_weight(const mpa_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
                           void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------ split-bf16 ("bf16x3") convolution, opt-in
+ * Same call sites as above, for the 15-row filters (double_conv of the 75x216 / 37x108 levels, unet_cnns.py:49-59;
+ * conv1 / prefilt_list, basic_cnns.py:371-387), stride 1.  Every fp32 operand is carried as hi + lo bf16 halves and a
+ * product is hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (error ~2e-5 of the result's rms:
+ * inside the 1e-4 forward bound; NOT bit-identical to the exact-fp32 path, which stays the default).
+ * Split activation layout: [B][ceil(C/8)][hi|lo][H][W][8 channels] bf16 (mpa_bf16x3_split_bytes() bytes).        */
+int64_t mpa_bf16x3_split_bytes(int B, int C, int H, int W);
+int mpa_bf16x3_split(const float* x, void* out, int B, int C, int H, int W, void* stream);
+/* 1 when the kernels are built for this problem (mode 0: forward, 1: backward-data, 2: backward-weight), else 0 */
+int mpa_conv2d_bf16x3_supported(const mpa_conv_desc* d, int mode);
+int64_t mpa_conv2d_bf16x3_packed_bytes(const mpa_conv_desc* d, int mode);
+int mpa_conv2d_bf16x3_pack(const mpa_conv_desc* d, int mode, const float* w, void* w_packed, void* stream);
+/* rows of `partials` ([rows][Cout][2], as mpa_conv2d_fwd_stats) the forward writes when partials != NULL */
+int64_t mpa_conv2d_bf16x3_stats_rows(const mpa_conv_desc* d);
+/* y = act(conv(x, w) + bias); xs from mpa_bf16x3_split(x), w_packed from mode 0; partials nullable (then act must be NONE) */
+int mpa_conv2d_bf16x3_fwd(const mpa_conv_desc* d, const void* xs, const void* w_packed, const float* bias, float* y, int act,
+                          float slope, float* partials, void* stream);
+/* dx = conv_transpose(dy, w); dys from mpa_bf16x3_split(dy) (Cout channels), w_packed from mode 1 */
+int mpa_conv2d_bf16x3_bwd_data(const mpa_conv_desc* d, const void* dys, const void* w_packed, float* dx, void* stream);
+
 /* ------------------------------------------------------------------ normalisation
  * Input LayerNorm([C,F]) applied on x.transpose(1,2) (unet_cnns.py:505,560;
  * basic_cnns.py:160,190): every (b,t) slice of C*F values is normalised jointly. */

@@ -58,6 +58,14 @@ SIGNATURES = {
     "mpa_conv2d_describe_plan": (c_int, [_D, c_int, ctypes.c_char_p, c_int]),
     "mpa_conv2d_bwd_weight_workspace": (c_int64, [_D]),
     "mpa_conv2d_bwd_weight": (c_int, [_D, _P, _P, _P, _P, _P, c_int64, _P]),
+    "mpa_bf16x3_split_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
+    "mpa_bf16x3_split": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "mpa_conv2d_bf16x3_supported": (c_int, [_D, c_int]),
+    "mpa_conv2d_bf16x3_packed_bytes": (c_int64, [_D, c_int]),
+    "mpa_conv2d_bf16x3_pack": (c_int, [_D, c_int, _P, _P, _P]),
+    "mpa_conv2d_bf16x3_stats_rows": (c_int64, [_D]),
+    "mpa_conv2d_bf16x3_fwd": (c_int, [_D, _P, _P, _P, _P, c_int, c_float, _P, _P]),
+    "mpa_conv2d_bf16x3_bwd_data": (c_int, [_D, _P, _P, _P, _P]),
     "mpa_layernorm_cf_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "mpa_layernorm_bwd_workspace": (c_int64, [c_int]),
     "mpa_layernorm_cf_bwd_ws": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

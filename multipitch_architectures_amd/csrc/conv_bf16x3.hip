@@ -1,0 +1,407 @@
+// Split-bf16 ("bf16x3") convolution for gfx950: every fp32 operand is carried as hi + lo bf16 halves and a product is
+// hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- 3 MFMAs at 16x the fp32-input MFMA rate,
+// error ~2e-5 of the result's rms on this model's data (scratch/split_bf16_error.py), inside the 1e-4 forward bound.
+// Opt-in (ops.set_conv_precision("bf16x3")); the exact-fp32 path of conv.hip stays the default and the headline.
+//
+// Replaces the same call sites as conv.hip for the 15-row filters: double_conv (unet_cnns.py:49-59) of the 75x216 and
+// 37x108 levels, conv1 / prefilt_list (basic_cnns.py:371-387).
+//
+// Layouts
+//   split activations  xs[b][c/8][hi|lo][y][x][8 channels]  bf16 -- one 16-byte granule = 8 channels of one pixel, the
+//                      K fragment one lane feeds to the MFMA; written by split_bf16_kernel (or a producing epilogue)
+//   packed filters     wp[cout tile 16][chunk 8 ch][q = dx quad][dy][hi|lo][lane 64][8 ch] -- one 1 KiB block is the A
+//                      operand of one MFMA exactly as the 64 lanes read it
+// Kernel (forward and, with flipped/transposed filters, backward-data): D[cout 16][pixel 16] per MFMA, K = 32 =
+// 8 channels x 4 horizontal taps.  A wave owns R output rows x 16 columns for one 16-cout tile and *slides* over the
+// input rows: the filter fragments of all KH vertical taps of the current (chunk, dx quad) sit in registers
+// (KH x 2 x 4 VGPRs), and input row d, read from LDS once, feeds every (output row, dy) pair with row + dy = d --
+// up to min(R, KH) x 3 MFMAs per pair of 16-byte LDS reads, which is what makes a 16-cout tile affordable
+// (without the slide a B fragment feeds 3 MFMAs and the LDS pipe, not the matrix pipe, sets the speed).
+// Bank conflicts: lanes n -> pixel f(n) (even pixels for n in {0-3,12-15}, odd for {4-11}) and k-groups g -> taps
+// (0,2,1,3) make every 16-lane ds_read_b128 group touch 16 distinct 16-byte slots.
+#include "mpa_common.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __attribute__((aligned(16))) uint4 bfx_zero[64];      // source of every out-of-image granule
+
+__device__ __forceinline__ void glds16(const uint4* src, uint4* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------ operand split
+// x fp32 [B][C][HW] -> out [B][C8][2][HW] granules of 8 bf16 (channels 8*c8 .. 8*c8+7 of one pixel; hi plane, lo plane)
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, uint4* __restrict__ out, int C, int C8,
+                                                         long HW, long total) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long pix = i % HW, t = i / HW;
+    const int c8 = (int)(t % C8);
+    const long b = t / C8;
+    const float* src = x + (b * C + (long)c8 * 8) * HW + pix;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {       // clamped address + mask: all eight loads go out together (no branch per element)
+      const int cj = c8 * 8 + j;
+      const float t0 = src[(long)(cj < C ? j : 0) * HW];
+      v[j] = cj < C ? t0 : 0.f;
+    }
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      hi[j] = (__bf16)v[j];
+      lo[j] = (__bf16)(v[j] - (float)hi[j]);
+    }
+    uint4* o = out + ((b * C8 + c8) * 2) * HW + pix;
+    o[0] = __builtin_bit_cast(uint4, hi);
+    o[HW] = __builtin_bit_cast(uint4, lo);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ filter packing
+struct BfxPackParams {
+  const float* w;
+  uint4* wp;
+  int Cout_w, Cin_w, kh, kw;     // original filter (Cout_w, Cin_w, kh, kw)
+  int mode;                      // 0: forward, 1: backward-data (flipped taps, channels transposed)
+  int CoutP, CinP;               // dims of the convolution that consumes the bank
+  int coTiles, nChunks, QN;
+  long total;                    // granules
+};
+
+__device__ __forceinline__ int bfx_tap_of_group(int g) { return g == 0 ? 0 : (g == 1 ? 2 : (g == 2 ? 1 : 3)); }
+
+__global__ __launch_bounds__(256) void bfx_pack_kernel(const BfxPackParams p) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < p.total; i += (long)gridDim.x * blockDim.x) {
+    long r = i;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int hl = (int)(r & 1); r >>= 1;
+    const int dy = (int)(r % p.kh); r /= p.kh;
+    const int q = (int)(r % p.QN); r /= p.QN;
+    const int chunk = (int)(r % p.nChunks); r /= p.nChunks;
+    const int cot = (int)r;
+    const int m = lane & 15, g = lane >> 4;
+    const int co = cot * 16 + m, dx = 4 * q + bfx_tap_of_group(g);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ci = chunk * 8 + j;
+      float v = 0.f;
+      if (co < p.CoutP && ci < p.CinP && dx < p.kw) {
+        if (p.mode == 0) v = p.w[(((long)co * p.Cin_w + ci) * p.kh + dy) * p.kw + dx];
+        else v = p.w[(((long)ci * p.Cin_w + co) * p.kh + (p.kh - 1 - dy)) * p.kw + (p.kw - 1 - dx)];
+      }
+      const __bf16 h = (__bf16)v;
+      o[j] = hl ? (__bf16)(v - (float)h) : h;
+    }
+    p.wp[i] = __builtin_bit_cast(uint4, o);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ convolution
+constexpr int BFX_PX = 128;        // LDS row pitch in granules: 7 waves x 16 columns + 15 taps, rounded up
+constexpr int BFX_MAXW = 7;        // waves (column blocks) per workgroup
+
+struct BfxParams {
+  const uint4* xs;
+  const uint4* wp;
+  const float* bias;
+  float* y;
+  float* stats;              // nullable: [nTilesAll][Cout][2] partial sums of y and y^2 (BatchNorm fusion)
+  int B, C8, H, W, Cout, OH, OW, QN, ph, pw;
+  int tilesY, tilesX, coTiles, nTilesAll, NW, act;
+  float slope;
+};
+
+template <int KH, int R>
+__global__ __launch_bounds__(512) void conv_bfx_kernel(const BfxParams p) {
+  constexpr int XR = R + KH - 1;                  // input rows of a tile
+  constexpr int XG = XR * 2 * BFX_PX;             // granules of the X image [row][hi|lo][BFX_PX]
+  constexpr int AG = KH * 2 * 64;                 // granules of one filter slab [dy][hi|lo][lane]
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+  uint4* lds_x = lds;
+  uint4* lds_a = lds + XG;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // XCD-aware order (as conv_fwd_kernel): the coTiles workgroups that stage the same input tile run back to back on one XCD
+  const int w = blockIdx.x;
+  const int seq = w >> 3;
+  const int cot = seq % p.coTiles;
+  int bid = (seq / p.coTiles) * 8 + (w & 7);
+  if (bid >= p.nTilesAll) return;
+  const int ptile = bid;
+  const int tx = bid % p.tilesX;
+  bid /= p.tilesX;
+  const int ty = bid % p.tilesY;
+  const int b = bid / p.tilesY;
+  const int oy0 = ty * R, ox0 = tx * (16 * p.NW);
+  const int iy0 = oy0 - p.ph, ix0 = ox0 - p.pw;
+  const int n = lane & 15, g = lane >> 4;
+  const int fn = n < 4 ? 2 * n : (n >= 12 ? 2 * (n - 8) : 2 * (n - 4) + 1);     // pixel of MFMA column n
+  const int xlane = wave * 16 + fn + bfx_tap_of_group(g);
+
+  f32x4 acc[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const long plane = (long)p.H * p.W;
+  const uint4* xsb = p.xs + (long)b * p.C8 * 2 * plane;
+  const int nslab = p.C8 * p.QN;
+  const uint4* wtile = p.wp + (long)cot * nslab * AG;
+  const uint4* zsrc = bfx_zero + (lane & 15);
+
+  auto stage_x = [&](int chunk) {
+    const uint4* src0 = xsb + (long)chunk * 2 * plane;
+    for (int i = wave; i < XG / 64; i += p.NW) {
+      const int e = i * 64 + lane;
+      const int px = e & (BFX_PX - 1), t = e >> 7;
+      const int hl = t & 1, d = t >> 1;
+      const int gy = iy0 + d, gx = ix0 + px;
+      const bool ok = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+      const long off = (long)hl * plane + (long)gy * p.W + gx;
+      glds16(ok ? src0 + off : zsrc, lds_x + i * 64);
+    }
+  };
+  auto stage_a = [&](int s) {
+    const uint4* src = wtile + (long)s * AG + lane;
+    for (int i = wave; i < KH * 2; i += p.NW) glds16(src + i * 64, lds_a + i * 64);
+  };
+
+  stage_x(0);
+  stage_a(0);
+  int s = 0;
+  for (int chunk = 0; chunk < p.C8; ++chunk) {
+    for (int q = 0; q < p.QN; ++q, ++s) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // slab s (and, at q == 0, the chunk's input tile) has landed
+      __builtin_amdgcn_s_barrier();
+      bf16x8 ah[KH], al[KH];
+#pragma unroll
+      for (int dy = 0; dy < KH; ++dy) {
+        ah[dy] = __builtin_bit_cast(bf16x8, lds_a[(dy * 2 + 0) * 64 + lane]);
+        al[dy] = __builtin_bit_cast(bf16x8, lds_a[(dy * 2 + 1) * 64 + lane]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                         // every wave holds the slab in registers: its buffer is free
+      if (s + 1 < nslab) stage_a(s + 1);                    // ... and the next slab streams in behind the MFMAs
+      const uint4* xb = lds_x + xlane + 4 * q;
+      // input row d+1 is requested before the MFMAs of row d are issued: its LDS latency hides behind them
+      bf16x8 bh = __builtin_bit_cast(bf16x8, xb[0]);
+      bf16x8 bl = __builtin_bit_cast(bf16x8, xb[BFX_PX]);
+#pragma unroll
+      for (int d = 0; d < XR; ++d) {
+        bf16x8 nh = bh, nl = bl;
+        if (d + 1 < XR) {
+          nh = __builtin_bit_cast(bf16x8, xb[(d * 2 + 2) * BFX_PX]);
+          nl = __builtin_bit_cast(bf16x8, xb[(d * 2 + 3) * BFX_PX]);
+        }
+#pragma unroll
+        for (int pb = 0; pb < R; ++pb) {
+          const int dy = d - pb;
+          if (dy >= 0 && dy < KH) {
+            acc[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[dy], bh, acc[pb], 0, 0, 0);
+            acc[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[dy], bl, acc[pb], 0, 0, 0);
+            acc[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[dy], bh, acc[pb], 0, 0, 0);
+          }
+        }
+        bh = nh; bl = nl;
+      }
+    }
+    if (chunk + 1 < p.C8) {
+      __builtin_amdgcn_s_barrier();                         // every wave is done with this chunk's input tile
+      stage_x(chunk + 1);
+    }
+  }
+
+  // epilogue: lane (n, g) holds couts 4g .. 4g+3 of pixel (row pb, column fn) of each of its R rows
+  const int ox = ox0 + wave * 16 + fn;
+  const bool colok = ox < p.OW;
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, qsum[4] = {0.f, 0.f, 0.f, 0.f};
+  float bs[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int co = cot * 16 + 4 * g + r;
+    bs[r] = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
+  }
+  float* yb = p.y + (long)b * p.Cout * p.OH * p.OW;
+#pragma unroll
+  for (int pb = 0; pb < R; ++pb) {
+    const int oy = oy0 + pb;
+    const bool ok = colok && oy < p.OH;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = cot * 16 + 4 * g + r;
+      float v = acc[pb][r] + bs[r];
+      if (ok) { ssum[r] += v; qsum[r] += v * v; }
+      v = mpa_apply_act(v, p.act, p.slope);
+      if (ok && co < p.Cout) yb[((long)co * p.OH + oy) * p.OW + ox] = v;
+    }
+  }
+  if (p.stats) {
+    __syncthreads();                                        // main-loop LDS images are dead
+    float* red = reinterpret_cast<float*>(lds);             // [wave][16 couts][2]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float sv = ssum[r], qv = qsum[r];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { sv += __shfl_xor(sv, o, 64); qv += __shfl_xor(qv, o, 64); }
+      if (n == 0) { red[(wave * 16 + 4 * g + r) * 2] = sv; red[(wave * 16 + 4 * g + r) * 2 + 1] = qv; }
+    }
+    __syncthreads();
+    const int co = cot * 16 + (int)threadIdx.x;
+    if (threadIdx.x < 16 && co < p.Cout) {
+      float s4 = 0.f, q4 = 0.f;
+      for (int wv = 0; wv < p.NW; ++wv) { s4 += red[(wv * 16 + threadIdx.x) * 2]; q4 += red[(wv * 16 + threadIdx.x) * 2 + 1]; }
+      *reinterpret_cast<float2*>(p.stats + ((long)ptile * p.Cout + co) * 2) = make_float2(s4, q4);
+    }
+  }
+}
+
+struct BfxPlan {
+  bool ok;
+  int R, NW, tilesY, tilesX, coTiles, C8, QN;
+  size_t lds_bytes;
+};
+
+// the convolution described by (Cin, H, W, Cout, kh, kw, ph, pw), stride 1
+BfxPlan bfx_plan(int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw) {
+  BfxPlan pl{};
+  pl.ok = false;
+  if (kh != 15 || kw < 1 || kw > 16 || sh != 1 || sw != 1) return pl;
+  const int OH = H + 2 * ph - kh + 1, OW = W + 2 * pw - kw + 1;
+  if (OH <= 0 || OW <= 0) return pl;
+  static const int forceR = getenv("MPA_BFX_R") ? atoi(getenv("MPA_BFX_R")) : 0;      // diagnostics
+  const int r15 = (int)mpa_cdiv(OH, 15) * 15, r13 = (int)mpa_cdiv(OH, 13) * 13;
+  pl.R = (r13 < r15) ? 13 : 15;
+  if (forceR == 13 || forceR == 15) pl.R = forceR;
+  pl.tilesY = (int)mpa_cdiv(OH, pl.R);
+  const int cb = (int)mpa_cdiv(OW, 16);
+  pl.tilesX = (int)mpa_cdiv(cb, BFX_MAXW);
+  pl.NW = (int)mpa_cdiv(cb, pl.tilesX);
+  pl.coTiles = (int)mpa_cdiv(Cout, 16);
+  pl.C8 = (int)mpa_cdiv(Cin, 8);
+  pl.QN = (int)mpa_cdiv(kw, 4);
+  pl.lds_bytes = ((size_t)(pl.R + kh - 1) * 2 * BFX_PX + (size_t)kh * 2 * 64) * 16;
+  pl.ok = true;
+  return pl;
+}
+
+struct BfxGeom { bool ok; int Cin, H, W, Cout, kh, kw, ph, pw; };
+
+BfxGeom bfx_geom(const mpa_conv_desc* d, int mode) {
+  BfxGeom g{};
+  g.ok = false;
+  if (!d || d->sh != 1 || d->sw != 1) return g;
+  const int OH = d->H + 2 * d->ph - d->kh + 1, OW = d->W + 2 * d->pw - d->kw + 1;
+  if (OH <= 0 || OW <= 0) return g;
+  if (mode == 0) {
+    g = BfxGeom{true, d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->ph, d->pw};
+  } else {
+    g = BfxGeom{true, d->Cout, OH, OW, d->Cin, d->kh, d->kw, d->kh - 1 - d->ph, d->kw - 1 - d->pw};
+    if (g.ph < 0 || g.pw < 0) g.ok = false;
+  }
+  return g;
+}
+
+int bfx_launch(const BfxGeom& g, int B, const void* xs, const void* wp, const float* bias, float* y, int act, float slope,
+               float* stats, hipStream_t s) {
+  const BfxPlan pl = bfx_plan(g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw);
+  if (!pl.ok) return MPA_ERR_UNSUPPORTED;
+  BfxParams p{};
+  p.xs = (const uint4*)xs; p.wp = (const uint4*)wp; p.bias = bias; p.y = y; p.stats = stats;
+  p.B = B; p.C8 = pl.C8; p.H = g.H; p.W = g.W; p.Cout = g.Cout;
+  p.OH = g.H + 2 * g.ph - g.kh + 1; p.OW = g.W + 2 * g.pw - g.kw + 1;
+  p.QN = pl.QN; p.ph = g.ph; p.pw = g.pw;
+  p.tilesY = pl.tilesY; p.tilesX = pl.tilesX; p.coTiles = pl.coTiles; p.nTilesAll = B * pl.tilesY * pl.tilesX;
+  p.NW = pl.NW; p.act = act; p.slope = slope;
+  const dim3 grid((unsigned)(mpa_cdiv(p.nTilesAll, 8) * 8 * pl.coTiles));
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv_bfx_kernel<15, 15>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_bfx_kernel<15, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  if (pl.R == 15) MPA_LAUNCH((conv_bfx_kernel<15, 15>), grid, dim3(64 * pl.NW), pl.lds_bytes, s, p);
+  else MPA_LAUNCH((conv_bfx_kernel<15, 13>), grid, dim3(64 * pl.NW), pl.lds_bytes, s, p);
+  return mpa_launch_status();
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+int64_t mpa_bf16x3_split_bytes(int B, int C, int H, int W) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return MPA_ERR_ARG;
+  return (int64_t)B * mpa_cdiv(C, 8) * 2 * H * W * 16;
+}
+
+int mpa_bf16x3_split(const float* x, void* out, int B, int C, int H, int W, void* stream) {
+  if (!x || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return MPA_ERR_ARG;
+  const int C8 = (int)mpa_cdiv(C, 8);
+  const long HW = (long)H * W, total = (long)B * C8 * HW;
+  const int blocks = (int)std::min<long>(mpa_cdiv(total, 256), 256 * 16);
+  MPA_LAUNCH(split_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (uint4*)out, C, C8, HW, total);
+  return mpa_launch_status();
+}
+
+int mpa_conv2d_bf16x3_supported(const mpa_conv_desc* d, int mode) {
+  const BfxGeom g = bfx_geom(d, mode);
+  if (!g.ok) return 0;
+  return bfx_plan(g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw).ok ? 1 : 0;
+}
+
+int64_t mpa_conv2d_bf16x3_packed_bytes(const mpa_conv_desc* d, int mode) {
+  const BfxGeom g = bfx_geom(d, mode);
+  if (!g.ok) return MPA_ERR_UNSUPPORTED;
+  const BfxPlan pl = bfx_plan(g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw);
+  if (!pl.ok) return MPA_ERR_UNSUPPORTED;
+  return (int64_t)pl.coTiles * pl.C8 * pl.QN * g.kh * 2 * 64 * 16;
+}
+
+int mpa_conv2d_bf16x3_pack(const mpa_conv_desc* d, int mode, const float* w, void* w_packed, void* stream) {
+  if (!w || !w_packed) return MPA_ERR_ARG;
+  const BfxGeom g = bfx_geom(d, mode);
+  if (!g.ok) return MPA_ERR_UNSUPPORTED;
+  const BfxPlan pl = bfx_plan(g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw);
+  if (!pl.ok) return MPA_ERR_UNSUPPORTED;
+  BfxPackParams p{};
+  p.w = w; p.wp = (uint4*)w_packed;
+  p.Cout_w = d->Cout; p.Cin_w = d->Cin; p.kh = d->kh; p.kw = d->kw; p.mode = mode;
+  p.CoutP = g.Cout; p.CinP = g.Cin; p.coTiles = pl.coTiles; p.nChunks = pl.C8; p.QN = pl.QN;
+  p.total = (long)pl.coTiles * pl.C8 * pl.QN * g.kh * 2 * 64;
+  const int blocks = (int)std::min<long>(mpa_cdiv(p.total, 256), 4096);
+  MPA_LAUNCH(bfx_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  return mpa_launch_status();
+}
+
+int64_t mpa_conv2d_bf16x3_stats_rows(const mpa_conv_desc* d) {
+  const BfxGeom g = bfx_geom(d, 0);
+  if (!g.ok) return MPA_ERR_UNSUPPORTED;
+  const BfxPlan pl = bfx_plan(g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw);
+  if (!pl.ok) return MPA_ERR_UNSUPPORTED;
+  return (int64_t)d->B * pl.tilesY * pl.tilesX;
+}
+
+int mpa_conv2d_bf16x3_fwd(const mpa_conv_desc* d, const void* xs, const void* w_packed, const float* bias, float* y, int act,
+                          float slope, float* partials, void* stream) {
+  if (!d || !xs || !w_packed || !y || d->B <= 0) return MPA_ERR_ARG;
+  if (partials && act != MPA_ACT_NONE) return MPA_ERR_UNSUPPORTED;
+  const BfxGeom g = bfx_geom(d, 0);
+  if (!g.ok) return MPA_ERR_UNSUPPORTED;
+  return bfx_launch(g, d->B, xs, w_packed, bias, y, act, slope, partials, (hipStream_t)stream);
+}
+
+int mpa_conv2d_bf16x3_bwd_data(const mpa_conv_desc* d, const void* dys, const void* w_packed, float* dx, void* stream) {
+  if (!d || !dys || !w_packed || !dx || d->B <= 0) return MPA_ERR_ARG;
+  const BfxGeom g = bfx_geom(d, 1);
+  if (!g.ok) return MPA_ERR_UNSUPPORTED;
+  if (g.H + 2 * g.ph - g.kh + 1 != d->H || g.W + 2 * g.pw - g.kw + 1 != d->W) return MPA_ERR_UNSUPPORTED;
+  return bfx_launch(g, d->B, dys, w_packed, nullptr, dx, MPA_ACT_NONE, 0.f, nullptr, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -206,6 +206,67 @@ def run_pack_table(tab):
         _pack_cache[wid] = (weakref.ref(w), sig, {k: _pack_buffers[(wid, k)][1] for k in keys})
 
 
+# --------------------------------------------------------------------------- split-bf16 ("bf16x3") convolution path
+class _Precision:
+    conv = "f32"          # "f32": exact fp32-input MFMA (default, the headline) | "bf16x3": hi/lo bf16 split, 3 MFMAs, fp32 acc
+
+
+def set_conv_precision(mode: str):
+    """Arithmetic of the convolutions that have a split-bf16 kernel (15-row filters, stride 1): "f32" (default) or
+    "bf16x3" -- every operand as hi + lo bf16 halves, products hi*hi + hi*lo + lo*hi accumulated in fp32.  The
+    bf16x3 path agrees with the reference to ~2e-5 of a layer output's rms (inside the 1e-4 forward bound) but is
+    not bit-identical to the exact path; layers without a bf16x3 kernel keep the exact one."""
+    if mode not in ("f32", "bf16x3"):
+        raise ValueError(f"conv precision must be 'f32' or 'bf16x3', got {mode!r}")
+    _Precision.conv = mode
+
+
+def get_conv_precision():
+    return _Precision.conv
+
+
+def _bfx_ok(desc, mode):
+    return _Precision.conv == "bf16x3" and bool(_lib().mpa_conv2d_bf16x3_supported(ctypes.byref(desc), mode))
+
+
+def split_bf16(x):
+    """fp32 (B,C,H,W) -> hi/lo bf16 planes [B][ceil(C/8)][2][H][W][8] (an int32 tensor of 4 words per 8-channel granule)"""
+    x = _c(x, "split input")
+    B, C, H, W = x.shape
+    out = torch.empty((B, (C + 7) // 8, 2, H, W, 4), dtype=torch.int32, device=x.device)
+    _chk(_lib().mpa_bf16x3_split(_p(x), _p(out), B, C, H, W, _s()), "mpa_bf16x3_split")
+    return out
+
+
+def _packed_bfx(weight, desc, mode):
+    """bf16x3 filter bank (mode 0 forward, 1 backward-data), cached like the fp32 banks until the weight changes"""
+    sig = (weight.data_ptr(), weight._version, _param_epoch)
+    ent = _bfx_cache.get(id(weight))
+    if ent is None or ent[0]() is not weight or ent[1] != sig:
+        old = ent[2] if ent is not None and ent[0]() is weight else {}
+        ent = (weakref.ref(weight), sig, {}, old)
+        _bfx_cache[id(weight)] = ent
+        if len(_bfx_cache) > 1024:
+            for k in [k for k, v in _bfx_cache.items() if v[0]() is None]:
+                del _bfx_cache[k]
+    key = (desc.key()[1:], mode)         # the bank does not depend on the batch size
+    buf = ent[2].get(key)
+    if buf is None:
+        lib = _lib()
+        n = lib.mpa_conv2d_bf16x3_packed_bytes(ctypes.byref(desc), mode)
+        if n < 0:
+            L.check(int(n), "mpa_conv2d_bf16x3_packed_bytes")
+        buf = ent[3].get(key)            # same storage as for the previous weight version (a captured graph packs into it)
+        if buf is None or buf.numel() * 4 != int(n):
+            buf = torch.empty(int(n) // 4, dtype=torch.int32, device=weight.device)
+        _chk(lib.mpa_conv2d_bf16x3_pack(ctypes.byref(desc), mode, _p(weight), _p(buf), _s()), "mpa_conv2d_bf16x3_pack")
+        ent[2][key] = buf
+    return buf
+
+
+_bfx_cache = {}
+
+
 # optional HIP-event probe around one class of conv launches (bench.py's live roofline measurement)
 class _Probe:
     match = None        # callable(desc_key, kind) -> bool
@@ -251,9 +312,27 @@ class Conv2dFn(torch.autograd.Function):
         if d.OH <= 0 or d.OW <= 0:
             raise RuntimeError(f"conv2d: kernel {(kh, kw)} larger than padded input {(H, W)}")
         y = torch.empty((B, Cout, d.OH, d.OW), dtype=torch.float32, device=x.device)
-        wp = _packed(weight, d, 0)
         ctx.desc, ctx.act, ctx.slope, ctx.has_bias = d, act, float(slope), bias is not None
         ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
+        if _bfx_ok(d, 0):
+            lib = _lib()
+            xs, wpb = split_bf16(x), _packed_bfx(weight, d, 0)
+            partials = None
+            if with_stats:
+                if act != ACT_NONE:
+                    raise RuntimeError("conv2d(with_stats=True) is the convolution in front of a BatchNorm: no activation")
+                rows = lib.mpa_conv2d_bf16x3_stats_rows(ctypes.byref(d))
+                if rows < 0:
+                    L.check(int(rows), "mpa_conv2d_bf16x3_stats_rows")
+                partials = torch.empty((int(rows), Cout, 2), dtype=torch.float32, device=x.device)
+            _chk(_probed("fwd", d, lambda: lib.mpa_conv2d_bf16x3_fwd(ctypes.byref(d), _p(xs), _p(wpb), _p(bias), _p(y), act,
+                                                                    float(slope), _p(partials), _s())),
+                 "mpa_conv2d_bf16x3_fwd")
+            if with_stats:
+                ctx.mark_non_differentiable(partials)
+                return y, partials
+            return y
+        wp = _packed(weight, d, 0)
         if with_stats:
             if act != ACT_NONE:
                 raise RuntimeError("conv2d(with_stats=True) is the convolution in front of a BatchNorm: no activation")
@@ -279,7 +358,12 @@ class Conv2dFn(torch.autograd.Function):
             _chk(lib.mpa_act_bwd(_p(dy), _p(y), _p(g), dy.numel(), ctx.act, ctx.slope, _s()), "mpa_act_bwd")
             dy = g
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and _bfx_ok(d, 1):
+            dx = torch.empty_like(x)
+            dys, wpb = split_bf16(dy), _packed_bfx(weight, d, 1)
+            _chk(_probed("dgrad", d, lambda: lib.mpa_conv2d_bf16x3_bwd_data(ctypes.byref(d), _p(dys), _p(wpb), _p(dx),
+                                                                           _s())), "mpa_conv2d_bf16x3_bwd_data")
+        elif ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             wp = _packed(weight, d, 1)
             _chk(_probed("dgrad", d, lambda: lib.mpa_conv2d_bwd_data(ctypes.byref(d), _p(dy), _p(wp), _p(dx), _s())),
