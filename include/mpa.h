@@ -99,6 +99,10 @@ int mpa_conv2d_bf16x3_fwd(const mpa_conv_desc* d, const void* xs, const void* w_
                           float slope, float* partials, void* stream);
 /* dx = conv_transpose(dy, w); dys from mpa_bf16x3_split(dy) (Cout channels), w_packed from mode 1 */
 int mpa_conv2d_bf16x3_bwd_data(const mpa_conv_desc* d, const void* dys, const void* w_packed, float* dx, void* stream);
+/* dw = sum dy * x, db = sum dy (db nullable) from the split input and the split output gradient; fixed-order reduction */
+int64_t mpa_conv2d_bf16x3_bwd_weight_workspace(const mpa_conv_desc* d);
+int mpa_conv2d_bf16x3_bwd_weight(const mpa_conv_desc* d, const void* xs, const void* dys, float* dw, float* db,
+                                 void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ normalisation
  * Input LayerNorm([C,F]) applied on x.transpose(1,2) (unet_cnns.py:505,560;

@@ -66,6 +66,8 @@ SIGNATURES = {
     "mpa_conv2d_bf16x3_stats_rows": (c_int64, [_D]),
     "mpa_conv2d_bf16x3_fwd": (c_int, [_D, _P, _P, _P, _P, c_int, c_float, _P, _P]),
     "mpa_conv2d_bf16x3_bwd_data": (c_int, [_D, _P, _P, _P, _P]),
+    "mpa_conv2d_bf16x3_bwd_weight_workspace": (c_int64, [_D]),
+    "mpa_conv2d_bf16x3_bwd_weight": (c_int, [_D, _P, _P, _P, _P, _P, c_int64, _P]),
     "mpa_layernorm_cf_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "mpa_layernorm_bwd_workspace": (c_int64, [c_int]),
     "mpa_layernorm_cf_bwd_ws": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

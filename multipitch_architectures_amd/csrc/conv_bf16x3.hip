@@ -330,6 +330,231 @@ int bfx_launch(const BfxGeom& g, int B, const void* xs, const void* wp, const fl
   return mpa_launch_status();
 }
 
+
+// ------------------------------------------------------------------------------------------------ backward-weight
+// dW[co][ci][dy][dx] = sum over pixels of dY[co][pixel] * X[ci][pixel + tap]: D[co 16][ci 16] per MFMA and tap, K = 32
+// consecutive pixels of one row.  Both operands want "lane = channel, 8 consecutive pixels" while the split tensors hold
+// "granule = pixel, 8 consecutive channels": ds_read_b64_tr_b16 transposes on the way out of LDS (two reads per fragment).
+// A workgroup = one (16-cout block, 16-channel block) and a slice of the column strips (image b, 32 columns); it walks a
+// strip top to bottom, WG_R rows of dY per step, with the input rows in a 32-row LDS ring (rows y-7 .. y+WG_R+6 live, the
+// next WG_R streaming in behind the MFMAs).  Wave v owns the horizontal taps dx = v and v + 8 and all 15 vertical ones
+// (2 x 15 accumulators): input row d, read once per dx, feeds every (dY row, dy) pair with row + dy = d -- the same slide
+// as the forward kernel.  The 16th dx slot (wave 7) accumulates the bias gradient (dY times ones) instead.
+// Partial sums per slice go to the workspace [S][Cout][Cin*225 + 1] (every element written exactly once), summed in a
+// fixed order by bfx_reduce_partials_kernel: run-to-run reproducible, no atomics.
+constexpr int WG_R = 8;
+constexpr int WG_RING = 32;                 // ring rows: slot(row) = (row + 9) & 31, so that 8-row blocks never wrap
+constexpr int WG_XP = 52;                   // X line pitch in granules: 32 + 14 columns, == 4 (mod 16): the two 8-channel
+constexpr int WG_DP = 36;                   // planes of a pixel sit 64 bytes apart (mod 256) -> conflict-free tr reads
+constexpr int WG_XROW = 4 * WG_XP;          // granules of one ring row: [hi|lo][c8 0|1][WG_XP]
+constexpr int WG_DROW = 4 * WG_DP;
+constexpr int WG_XG = WG_RING * WG_XROW;    // 6656 granules
+constexpr int WG_DG = WG_R * WG_DROW;       // 1152 granules per dY buffer (two buffers)
+
+struct BfxWgParams {
+  const uint4* xs;        // split input  [B][XC8][2][H][W]
+  const uint4* dys;       // split grad   [B][DC8][2][OH][OW]
+  float* ws;              // [S][Cout][NtotP]
+  int B, Cin, XC8, H, W, Cout, DC8, OH, OW, kw, ph, pw;
+  int tilesX, strips, S, steps, NtotP, ciBlocks;
+};
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 bfx_tr_frag(const char* lds_addr) {
+  // two transposing reads: pixels 8g .. 8g+3 and 8g+4 .. 8g+7 of this lane's channel
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(lds_addr));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(lds_addr + 64));
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+__global__ __launch_bounds__(512) void conv_bfx_wgrad_kernel(const BfxWgParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+  uint4* lds_x = lds;
+  uint4* lds_d = lds + WG_XG;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int slice = blockIdx.x, cib = blockIdx.y, cob = blockIdx.z;
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+  const bool has2 = wave + 8 < p.kw;                      // second dx slot of this wave is a real tap
+  const bool dbwave = (wave + 8 == 15) || (p.kw <= 8 && wave == 7);
+
+  f32x4 acc[2][15];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 15; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // per-lane byte offset of a transposing read inside a line pair [c8 0][c8 1]: row q of the 4-pixel block, channels 4pp..
+  const int lane_x = (((pp >> 1) * WG_XP + 8 * g + q) * 16) + (pp & 1) * 8;
+  const int lane_d = (((pp >> 1) * WG_DP + 8 * g + q) * 16) + (pp & 1) * 8;
+  const char* xbase = reinterpret_cast<const char*>(lds_x) + lane_x;
+  const char* dbase = reinterpret_cast<const char*>(lds_d) + lane_d;
+  const uint4* zsrc = bfx_zero + (lane & 15);
+  const long xplane = (long)p.H * p.W, dplane = (long)p.OH * p.OW;
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+
+  for (int strip = slice; strip < p.strips; strip += p.S) {
+    const int b = strip / p.tilesX, tx = strip - b * p.tilesX;
+    const int x0 = tx * 32;
+    const uint4* xsb = p.xs + ((long)b * p.XC8 + cib * 2) * 2 * xplane;
+    const uint4* dsb = p.dys + ((long)b * p.DC8 + cob * 2) * 2 * dplane;
+    // X rows [row0, row0 + nrows) -> ring slots from slot0 (nrows % 4 == 0, no wrap inside a block)
+    auto stage_x = [&](int slot0, int row0, int nrows) {
+      const int ninstr = nrows * WG_XROW / 64;
+      for (int i = wave; i < ninstr; i += 8) {
+        const int e = i * 64 + lane;
+        const int line = e / WG_XP, px = e - line * WG_XP;
+        const int row = line >> 2, hl = (line >> 1) & 1, c8 = line & 1;
+        const int gy = row0 + row, gx = x0 - p.pw + px;
+        const bool ok = px < 32 + p.kw - 1 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W &&
+                        cib * 2 + c8 < p.XC8;
+        const long off = ((long)c8 * 2 + hl) * xplane + (long)gy * p.W + gx;
+        glds16(ok ? xsb + off : zsrc, lds_x + slot0 * WG_XROW + i * 64);
+      }
+    };
+    auto stage_d = [&](int buf, int row0) {
+      for (int i = wave; i < WG_DG / 64; i += 8) {
+        const int e = i * 64 + lane;
+        const int line = e / WG_DP, px = e - line * WG_DP;
+        const int row = line >> 2, hl = (line >> 1) & 1, c8 = line & 1;
+        const int gy = row0 + row, gx = x0 + px;
+        const bool ok = px < 32 && gy < p.OH && gx < p.OW && cob * 2 + c8 < p.DC8;
+        const long off = ((long)c8 * 2 + hl) * dplane + (long)gy * p.OW + gx;
+        glds16(ok ? dsb + off : zsrc, lds_d + buf * WG_DG + i * 64);
+      }
+    };
+    __builtin_amdgcn_s_barrier();                      // the previous strip's last reads are done
+    stage_x(0, -p.ph - 2, 24);                         // slot(row) = (row + ph + 2) & 31: rows -ph-2 .. -ph+21 in slots 0 .. 23
+    stage_d(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < p.steps; ++t) {
+      const int y0 = t * WG_R;
+      if (t + 1 < p.steps) {                           // next step's rows stream in behind this step's MFMAs
+        stage_x((8 * t + 24) & 31, y0 - p.ph + 22, 8);
+        stage_d((t + 1) & 1, y0 + WG_R);
+      }
+      const char* db_ = dbase + (t & 1) * (WG_DG * 16);
+      bf16x8 ah[WG_R], al[WG_R];
+#pragma unroll
+      for (int y = 0; y < WG_R; ++y) {
+        ah[y] = bfx_tr_frag(db_ + (y * WG_DROW) * 16);
+        al[y] = bfx_tr_frag(db_ + (y * WG_DROW + 2 * WG_DP) * 16);
+      }
+#pragma unroll
+      for (int sd = 0; sd < 2; ++sd) {
+        if (sd == 1 && !has2) {
+          if (dbwave && cib == 0) {                    // bias gradient: dY (hi + lo) times ones, all columns equal
+#pragma unroll
+            for (int y = 0; y < WG_R; ++y) {
+              acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[y], ones, acc[1][0], 0, 0, 0);
+              acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[y], ones, acc[1][0], 0, 0, 0);
+            }
+          }
+          continue;
+        }
+        if (sd == 0 && wave >= p.kw) continue;
+        const int dx = wave + 8 * sd;
+        const char* xb = xbase + dx * 16;
+#pragma unroll
+        for (int d = 0; d < WG_R + 14; ++d) {
+          const int slot = (8 * t + 2 + d) & 31;       // ring slot of input row y0 - ph + d (wave-uniform)
+          const char* xr = xb + slot * (WG_XROW * 16);
+          const bf16x8 bh = bfx_tr_frag(xr);
+          const bf16x8 bl = bfx_tr_frag(xr + 2 * WG_XP * 16);
+#pragma unroll
+          for (int y = 0; y < WG_R; ++y) {
+            const int dy = d - y;
+            if (dy >= 0 && dy < 15) {
+              acc[sd][dy] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[y], bh, acc[sd][dy], 0, 0, 0);
+              acc[sd][dy] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[y], bl, acc[sd][dy], 0, 0, 0);
+              acc[sd][dy] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[y], bh, acc[sd][dy], 0, 0, 0);
+            }
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                    // next step's rows have landed; this step's reads are done
+    }
+  }
+
+  // lane (n = i16, g) holds dW[co = 4g + r][ci = n] of each of its taps
+  const int ci = cib * 16 + i16;
+  float* wsb = p.ws + (long)slice * p.Cout * p.NtotP;
+#pragma unroll
+  for (int sd = 0; sd < 2; ++sd) {
+    const int dx = wave + 8 * sd;
+    if (dx < p.kw && ci < p.Cin) {
+#pragma unroll
+      for (int dy = 0; dy < 15; ++dy)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = cob * 16 + 4 * g + r;
+          if (co < p.Cout) wsb[(long)co * p.NtotP + ((long)ci * 15 + dy) * p.kw + dx] = acc[sd][dy][r];
+        }
+    }
+  }
+  if (dbwave && cib == 0 && i16 == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = cob * 16 + 4 * g + r;
+      if (co < p.Cout) wsb[(long)co * p.NtotP + p.NtotP - 1] = acc[1][0][r];
+    }
+  }
+}
+
+// ws [S][Cout][NtotP] -> dw [Cout][Ntot] (+ db [Cout] from the last column); eight independent chains, fixed order
+__global__ void bfx_reduce_partials_kernel(const float* __restrict__ ws, float* __restrict__ dw, float* __restrict__ db,
+                                           int Cout, int Ntot, int NtotP, int S) {
+  const long n = (long)Cout * NtotP;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = 0.f;
+    const float* src = ws + i;
+    int k = 0;
+    for (; k + 8 <= S; k += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += src[(long)(k + u) * n];
+    }
+    for (; k < S; ++k) a[k & 7] += src[(long)k * n];
+    const float sum = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    const int co = (int)(i / NtotP), j = (int)(i - (long)co * NtotP);
+    if (j < Ntot) dw[(long)co * Ntot + j] = sum;
+    else if (db) db[co] = sum;
+  }
+}
+
+struct BfxWgPlan { bool ok; int tilesX, strips, S, steps, coBlocks, ciBlocks, NtotP; };
+
+BfxWgPlan bfx_wg_plan(const mpa_conv_desc* d) {
+  BfxWgPlan pl{};
+  pl.ok = false;
+  if (!d || d->kh != 15 || d->kw < 1 || d->kw > 15 || d->sh != 1 || d->sw != 1) return pl;
+  const int OH = d->H + 2 * d->ph - d->kh + 1, OW = d->W + 2 * d->pw - d->kw + 1;
+  if (OH <= 0 || OW <= 0 || d->ph < 0 || d->ph > 14) return pl;
+  pl.tilesX = (int)mpa_cdiv(OW, 32);
+  pl.strips = d->B * pl.tilesX;
+  pl.steps = (int)mpa_cdiv(OH, WG_R);
+  pl.coBlocks = (int)mpa_cdiv(d->Cout, 16);
+  pl.ciBlocks = (int)mpa_cdiv(d->Cin, 16);
+  const int groups = pl.coBlocks * pl.ciBlocks;
+  static const int forceS = getenv("MPA_BFX_WG_S") ? atoi(getenv("MPA_BFX_WG_S")) : 0;      // diagnostics
+  int S = std::max(1, std::min(pl.strips, 256 / std::max(1, groups)));
+  S = (int)mpa_cdiv(pl.strips, mpa_cdiv(pl.strips, S));                   // equal strips per slice
+  if (forceS >= 1 && forceS <= pl.strips) S = forceS;
+  pl.S = S;
+  pl.NtotP = d->Cin * d->kh * d->kw + 1;
+  pl.ok = true;
+  return pl;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ C ABI
@@ -350,6 +575,7 @@ int mpa_bf16x3_split(const float* x, void* out, int B, int C, int H, int W, void
 }
 
 int mpa_conv2d_bf16x3_supported(const mpa_conv_desc* d, int mode) {
+  if (mode == 2) return bfx_wg_plan(d).ok ? 1 : 0;
   const BfxGeom g = bfx_geom(d, mode);
   if (!g.ok) return 0;
   return bfx_plan(g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw).ok ? 1 : 0;
@@ -402,6 +628,42 @@ int mpa_conv2d_bf16x3_bwd_data(const mpa_conv_desc* d, const void* dys, const vo
   if (!g.ok) return MPA_ERR_UNSUPPORTED;
   if (g.H + 2 * g.ph - g.kh + 1 != d->H || g.W + 2 * g.pw - g.kw + 1 != d->W) return MPA_ERR_UNSUPPORTED;
   return bfx_launch(g, d->B, dys, w_packed, nullptr, dx, MPA_ACT_NONE, 0.f, nullptr, (hipStream_t)stream);
+}
+
+int64_t mpa_conv2d_bf16x3_bwd_weight_workspace(const mpa_conv_desc* d) {
+  const BfxWgPlan pl = bfx_wg_plan(d);
+  if (!pl.ok) return MPA_ERR_UNSUPPORTED;
+  return (int64_t)pl.S * d->Cout * pl.NtotP * 4;
+}
+
+int mpa_conv2d_bf16x3_bwd_weight(const mpa_conv_desc* d, const void* xs, const void* dys, float* dw, float* db,
+                                 void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!d || !xs || !dys || !dw || d->B <= 0) return MPA_ERR_ARG;
+  const BfxWgPlan pl = bfx_wg_plan(d);
+  if (!pl.ok) return MPA_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < (int64_t)pl.S * d->Cout * pl.NtotP * 4) return MPA_ERR_WORKSPACE;
+  BfxWgParams p{};
+  p.xs = (const uint4*)xs; p.dys = (const uint4*)dys; p.ws = (float*)workspace;
+  p.B = d->B; p.Cin = d->Cin; p.XC8 = (int)mpa_cdiv(d->Cin, 8); p.H = d->H; p.W = d->W;
+  p.Cout = d->Cout; p.DC8 = (int)mpa_cdiv(d->Cout, 8);
+  p.OH = d->H + 2 * d->ph - d->kh + 1; p.OW = d->W + 2 * d->pw - d->kw + 1;
+  p.kw = d->kw; p.ph = d->ph; p.pw = d->pw;
+  p.tilesX = pl.tilesX; p.strips = pl.strips; p.S = pl.S; p.steps = pl.steps; p.NtotP = pl.NtotP; p.ciBlocks = pl.ciBlocks;
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv_bfx_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  const size_t lds_bytes = (size_t)(WG_XG + 2 * WG_DG) * 16;
+  MPA_LAUNCH(conv_bfx_wgrad_kernel, dim3((unsigned)pl.S, (unsigned)pl.ciBlocks, (unsigned)pl.coBlocks), dim3(512), lds_bytes, s, p);
+  int rc = mpa_launch_status();
+  if (rc) return rc;
+  const int Ntot = pl.NtotP - 1;
+  const long n = (long)d->Cout * pl.NtotP;
+  MPA_LAUNCH(bfx_reduce_partials_kernel, dim3((unsigned)std::min<long>(mpa_cdiv(n, 256), 2048)), dim3(256), 0, s,
+             (const float*)workspace, dw, db, d->Cout, Ntot, pl.NtotP, pl.S);
+  return mpa_launch_status();
 }
 
 }  // extern "C"

@@ -313,10 +313,13 @@ class Conv2dFn(torch.autograd.Function):
             raise RuntimeError(f"conv2d: kernel {(kh, kw)} larger than padded input {(H, W)}")
         y = torch.empty((B, Cout, d.OH, d.OW), dtype=torch.float32, device=x.device)
         ctx.desc, ctx.act, ctx.slope, ctx.has_bias = d, act, float(slope), bias is not None
-        ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
+        ctx.bfx_xs = False
         if _bfx_ok(d, 0):
             lib = _lib()
             xs, wpb = split_bf16(x), _packed_bfx(weight, d, 0)
+            # the backward-weight kernel reads the split input: keep that instead of x (same number of bytes)
+            ctx.bfx_xs = bool(lib.mpa_conv2d_bf16x3_supported(ctypes.byref(d), 2))
+            ctx.save_for_backward(xs if ctx.bfx_xs else x, weight, y if act != ACT_NONE else None)
             partials = None
             if with_stats:
                 if act != ACT_NONE:
@@ -332,6 +335,7 @@ class Conv2dFn(torch.autograd.Function):
                 ctx.mark_non_differentiable(partials)
                 return y, partials
             return y
+        ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
         wp = _packed(weight, d, 0)
         if with_stats:
             if act != ACT_NONE:
@@ -358,17 +362,33 @@ class Conv2dFn(torch.autograd.Function):
             _chk(lib.mpa_act_bwd(_p(dy), _p(y), _p(g), dy.numel(), ctx.act, ctx.slope, _s()), "mpa_act_bwd")
             dy = g
         dx = dw = db = None
+        dys = None
+        x_shape = (d.B, d.Cin, d.H, d.W)
         if ctx.needs_input_grad[0] and _bfx_ok(d, 1):
-            dx = torch.empty_like(x)
+            dx = torch.empty(x_shape, dtype=torch.float32, device=dy.device)
             dys, wpb = split_bf16(dy), _packed_bfx(weight, d, 1)
             _chk(_probed("dgrad", d, lambda: lib.mpa_conv2d_bf16x3_bwd_data(ctypes.byref(d), _p(dys), _p(wpb), _p(dx),
                                                                            _s())), "mpa_conv2d_bf16x3_bwd_data")
         elif ctx.needs_input_grad[0]:
+            if ctx.bfx_xs:
+                raise RuntimeError("conv precision changed between the forward and the backward pass of a convolution")
             dx = torch.empty_like(x)
             wp = _packed(weight, d, 1)
             _chk(_probed("dgrad", d, lambda: lib.mpa_conv2d_bwd_data(ctypes.byref(d), _p(dy), _p(wp), _p(dx), _s())),
                  "mpa_conv2d_bwd_data")
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and ctx.bfx_xs:
+            dw = torch.empty_like(weight)
+            db = torch.empty(d.Cout, dtype=torch.float32, device=dy.device) if ctx.has_bias else None
+            if dys is None:
+                dys = split_bf16(dy)
+            nbytes = lib.mpa_conv2d_bf16x3_bwd_weight_workspace(ctypes.byref(d))
+            if nbytes < 0:
+                L.check(int(nbytes), "mpa_conv2d_bf16x3_bwd_weight_workspace")
+            ws = torch.empty(int(nbytes) // 4, dtype=torch.float32, device=dy.device)
+            _chk(_probed("wgrad", d, lambda: lib.mpa_conv2d_bf16x3_bwd_weight(ctypes.byref(d), _p(x), _p(dys), _p(dw), _p(db),
+                                                                              _p(ws), int(nbytes), _s())),
+                 "mpa_conv2d_bf16x3_bwd_weight")
+        elif ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(weight)
             db = torch.empty(d.Cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
             nbytes = lib.mpa_conv2d_bwd_weight_workspace(ctypes.byref(d))

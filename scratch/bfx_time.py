@@ -23,9 +23,13 @@ for cin, cout, H, W in LAYERS:
         res[prec, "fwd"] = t(lambda: ops.conv2d(x, w, None, (1, 1), (7, 7)))
         y = ops.conv2d(xr, w, None, (1, 1), (7, 7))
         res[prec, "dgrad"] = t(lambda: torch.autograd.grad(y, xr, dy, retain_graph=True))
+        wr = w.clone().requires_grad_(True)
+        y2 = ops.conv2d(x, wr, None, (1, 1), (7, 7))
+        res[prec, "wgrad"] = t(lambda: torch.autograd.grad(y2, wr, dy, retain_graph=True))
     if True:
         ops.set_conv_precision("bf16x3")
         res["split", "x"] = t(lambda: ops.split_bf16(x)); res["split", "dy"] = t(lambda: ops.split_bf16(dy))
     print(f"{cin:3d}->{cout:3d} {H}x{W} B={B}: fwd f32 {res['f32','fwd']:7.3f} ms ({flop/res['f32','fwd']/1e9:6.1f} TF)  bf16x3 {res['bf16x3','fwd']:7.3f} ms "
           f"({flop/res['bf16x3','fwd']/1e9:6.1f} TF incl. split {res['split','x']:.3f}) | dgrad f32 {res['f32','dgrad']:7.3f}  bf16x3 {res['bf16x3','dgrad']:7.3f} ms "
-          f"({flop/res['bf16x3','dgrad']/1e9:6.1f} TF incl. split {res['split','dy']:.3f})", flush=True)
+          f"({flop/res['bf16x3','dgrad']/1e9:6.1f} TF incl. split {res['split','dy']:.3f}) | wgrad f32 {res['f32','wgrad']:7.3f}  bf16x3 {res['bf16x3','wgrad']:7.3f} ms "
+          f"({flop/res['bf16x3','wgrad']/1e9:6.1f} TF incl. split)", flush=True)

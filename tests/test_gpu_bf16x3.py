@@ -59,6 +59,24 @@ def test_conv_forward_backward_data_match_float64(dev, geom):
     assert gerr <= 1e-4 * max(xr.grad.abs().max().item(), 1.0), f"backward-data error {gerr:.3e}"
 
 
+@pytest.mark.parametrize("geom", GEOMS, ids=lambda g: "x".join(map(str, g)))
+def test_conv_backward_weight_and_bias_match_float64(dev, geom):
+    B, Cin, H, W, Cout, kw, pw = geom
+    x = _data((B, Cin, H, W), 11, hcqt=True)
+    w = _data((Cout, Cin, 15, kw), 12) / np.sqrt(Cin * 15 * kw)
+    b = _data((Cout,), 13)
+    wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = ops.conv2d(x.to(dev), wd, bd, (1, 1), (7 if pw else 0, pw))
+    dy = _data(tuple(y.shape), 14)
+    y.backward(dy.to(dev))
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    F.conv2d(x.double(), wr, br, padding=(7 if pw else 0, pw)).backward(dy.double())
+    werr = (wd.grad.cpu().double() - wr.grad).abs().max().item()
+    assert werr <= 1e-4 * max(wr.grad.abs().max().item(), 1.0), f"backward-weight error {werr:.3e} (max {wr.grad.abs().max():.3f})"
+    berr = (bd.grad.cpu().double() - br.grad).abs().max().item()
+    assert berr <= 1e-4 * max(br.grad.abs().max().item(), 1.0), f"bias gradient error {berr:.3e}"
+
+
 def test_fused_activation_and_batchnorm_partials(dev):
     B, Cin, H, W, Cout = 2, 16, 37, 108, 32
     x, w, b = _data((B, Cin, H, W), 5, hcqt=True), _data((Cout, Cin, 15, 15), 6) / 60.0, _data((Cout,), 7)
