@@ -32,6 +32,10 @@ def parse_args(argv=None):
                     "probes after the timed region (profiling runs)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying "
                     "the captured HIP graph of the step")
+    ap.add_argument("--conv-precision", choices=("f32", "bf16x3"), default="f32",
+                    help="arithmetic of the 15-row convolutions: exact fp32-input MFMA (default, the headline) or the opt-in "
+                    "split-bf16 path (hi*hi + hi*lo + lo*hi on bf16 MFMA, fp32 accumulation); the bf16x3 line carries "
+                    "dtype 'bf16x3-f32acc' and its roofline against the bf16 MFMA peak / 3")
     ap.add_argument("--dp-rehearsal", action="store_true", help="with --gpus 1: run what a data-parallel rank runs (RCCL "
                     "process group of one rank, gradient hooks, bucketed asynchronous all-reduces, kernel-by-kernel "
                     "step) -- the per-rank cost of the data-parallel machinery on a one-GPU box; not a BASELINE line")
@@ -90,6 +94,7 @@ import torch  # noqa: E402  (after the spawn decision: the parent of an N>1 run 
 
 PROBE_STEPS = 3
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X dense fp32-input MFMA peak (MI355X_MICROARCH.md, chip table)
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA peak (same table); a split-bf16 product costs three MFMAs
 
 
 def cpu_baseline(config, frames, sample_batch=8, steps=2):
@@ -233,6 +238,45 @@ def segment_inference_probe(model, n_frames=2000, segment=100):
     return res
 
 
+def bf16x3_probe(model, criterion, opt, x, y, args, probe, kflops, gflop_table):
+    """The same training step with the opt-in split-bf16 convolutions (ops.set_conv_precision("bf16x3")), timed after the
+    headline region: a second, clearly labelled measurement -- never the line's `value`."""
+    from multipitch_architectures_amd import ops
+    from multipitch_architectures_amd.step import TrainStep
+    ops.set_conv_precision("bf16x3")
+    try:
+        ts = TrainStep(model, criterion, opt, use_graph=not args.no_graph)
+        for _ in range(3):
+            ts(x, y)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ts(x, y)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        ops.set_kernel_probe(probe)
+        for _ in range(PROBE_STEPS):
+            ts.eager(x, y)
+        pm = ops.probe_results_ms()
+        ops.set_kernel_probe(None)
+    finally:
+        ops.set_conv_precision("f32")
+    kms = sum(pm) / max(len(pm), 1)
+    peak = PEAK_BF16_MFMA_TFLOPS / 3.0
+    ach = kflops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+    res = {"dtype": "bf16x3-f32acc", "ms_per_step": dt * 1e3, "value": args.global_batch * (args.frames - 74) / dt,
+           "unit": "frames/s", "hip_graph": ts.graph is not None,
+           "note": "opt-in (bench.py --conv-precision bf16x3): the 15-row convolutions as hi/lo bf16 halves, three bf16 "
+                   "MFMAs per product, fp32 accumulation; everything else as in the headline run",
+           "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                        "launch_ms": kms, "launches_timed": len(pm),
+                        "kernel": "operand split + conv_bfx_kernel of the headline line's roofline layer",
+                        "peak_note": "dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per product"}}
+    if args.config in gflop_table and args.frames == 75:
+        res["step_tflops"] = gflop_table[args.config] * args.global_batch / dt / 1e3
+    return res
+
+
 def main():
     args = parse_args()
 
@@ -293,6 +337,9 @@ def main():
     x, y = synth_batch(args.global_batch, args.frames, seed=1234)
     x, y = x[lo:hi].to(dev), y[lo:hi].to(dev)               # inputs resident in HBM before the timed region
     ops.manual_seed(1234 + rank)
+    ops.set_conv_precision(args.conv_precision)
+    bfx = args.conv_precision == "bf16x3"
+    peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if bfx else PEAK_FP32_MFMA_TFLOPS
 
     criterion = (lambda res, t: loss_fn(res[0], res[1], t)) if is_punet else loss_fn
     # the reference's loop body; replayed as one captured HIP graph after the first (eager) steps unless --no-graph
@@ -376,7 +423,7 @@ def main():
         traffic = mfma_busy = None
         for tfile in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             tfile = os.path.join(ROOT, "profiles", tfile)
-            if os.path.exists(tfile) and args.config == "SAUnet:L" and B_loc == 256 and args.frames == 75:
+            if os.path.exists(tfile) and args.config == "SAUnet:L" and B_loc == 256 and args.frames == 75 and not bfx:
                 tj = json.load(open(tfile))
                 traffic, mfma_busy = tj["traffic_bytes"], tj.get("mfma_busy")
                 break
@@ -384,7 +431,8 @@ def main():
         out = {
             "metric": "HCQT frames/sec (train step), SAUnet:L" if args.config == "SAUnet:L" else f"HCQT frames/sec (train step), {args.config}",
             "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16x3-f32acc" if bfx else "f32",
             "data": "synthetic", "patches_per_s": patches_per_s, "loss": float(loss.detach()),
             "ranks_seen": dist.get_world_size() if dp else 1, "devices": devices,
             "dist_backend": backend if dp else None, "dp_rehearsal": bool(args.dp_rehearsal and world == 1),
@@ -394,9 +442,12 @@ def main():
                                       if args.config in baseline_batch and args.global_batch == baseline_batch[args.config]
                                       else "not a BASELINE.json configuration"), "global_batch": args.global_batch,
                        "frames": args.frames, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "mfma_busy": mfma_busy,
-                         "kernel": f"conv_fwd_kernel {dom.in_channels}->{dom.out_channels} "
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic, "mfma_busy": mfma_busy,
+                         "peak_note": ("dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per split-bf16 product; the launch "
+                                       "includes the operand-split kernel in front of the convolution") if bfx else
+                                      "dense fp32-input MFMA peak",
+                         "kernel": f"{'conv_bfx_kernel' if bfx else 'conv_fwd_kernel'} {dom.in_channels}->{dom.out_channels} "
                                    f"{dom.kernel_size[0]}x{dom.kernel_size[1]} @{H}x{W} ({dom_name}), local batch {B_loc}",
                          "launch_ms": kms,
                          "launches_timed": len(probe_ms), "algorithmic_gflop_per_launch": kflops / 1e9,
@@ -408,8 +459,13 @@ def main():
             step_tflops = TRAIN_GFLOP_PER_PATCH[args.config] * patches_per_s / 1e3
             out["step_tflops"] = step_tflops
             out["step_mfma_frac"] = step_tflops / (PEAK_FP32_MFMA_TFLOPS * world)
+            if bfx:
+                out["step_mfma_frac_note"] = ("against the fp32-input MFMA peak (157.3): only the 15-row convolutions run on "
+                                              "bf16 MFMA, so values above 1 are expected")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, args.frames)
+        if world == 1 and not args.no_extras and not bfx and not args.dp_rehearsal:
+            out["bf16x3"] = bf16x3_probe(model, criterion, opt, x, y, args, probe, kflops, TRAIN_GFLOP_PER_PATCH)
         if world == 1 and not args.no_extras:
             out["patch_extraction"] = patch_extraction_probe(B_loc, not args.no_cpu_baseline)
             out["eval_measures"] = eval_measures_probe(not args.no_cpu_baseline)
