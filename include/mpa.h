@@ -281,6 +281,19 @@ int64_t mpa_eval_measures_workspace(int64_t n_frames, int n_bins);
 int mpa_eval_measures(const float* targ, const float* pred, int64_t n_frames, int n_bins, double threshold,
                       double* out, void* ws, int64_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------ note list -> piano roll
+ * replaces compute_annotation_array_nooverlap (libdl/data_preprocessing/hcqt.py:205-272; called by
+ * 01_precompute_features.ipynb cell 7).  note_events: device array [n_events][ev_stride >= 3] of float64 rows
+ * (start_sec, end_sec, pitch, ...); kind 0 'pitch_class' (12 rows), 1 'pitch' (128 rows), 2 'instruments' (1 row);
+ * out: device float64 [rows][n_frames] (zeroed inside).  Integer / index work: bit-exact with the reference.
+ * workspace: mpa_annotation_workspace(n_events) bytes; its first int32 is the status the caller must read after the
+ * stream has finished: 0 ok, 1 the reference's assertion fired ("still events of length<1 after correction!"),
+ * 2 a row index out of bounds (numpy's IndexError), 3 more than 8192 vanishing events (not built).              */
+int64_t mpa_annotation_workspace(int n_events);
+int mpa_annotation_array_nooverlap(const double* note_events, int ev_stride, int n_events, double fs_hcqt, double shorten,
+                                   int kind, int n_frames, double* out, void* workspace, int64_t workspace_bytes,
+                                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

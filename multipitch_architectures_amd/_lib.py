@@ -109,6 +109,8 @@ SIGNATURES = {
     "mpa_context_batch": (c_int, [ctypes.POINTER(ContextDesc), c_int, _P, _P, _P, _P, _P, _P, _P, ctypes.c_uint64, _P, _P, _P]),
     "mpa_eval_measures_workspace": (c_int64, [c_int64, c_int]),
     "mpa_eval_measures": (c_int, [_P, _P, c_int64, c_int, c_double, _P, _P, c_int64, _P]),
+    "mpa_annotation_workspace": (c_int64, [c_int]),
+    "mpa_annotation_array_nooverlap": (c_int, [_P, c_int, c_int, c_double, c_double, c_int, c_int, _P, _P, c_int64, _P]),
     "mpa_adamw_step": (c_int, [_P, _P, _P, _P, _P, c_int, c_int64, _P, c_double, c_double, c_double, c_double, _P]),
 }
 
