@@ -279,6 +279,11 @@ def bf16x3_probe(model, criterion, opt, x, y, args, probe, kflops, gflop_table):
 
 def main():
     args = parse_args()
+    # stdout carries exactly ONE line, the JSON: libraries that print banners to file descriptor 1 (RCCL's version block
+    # at communicator creation) are sent to stderr for the whole run, the line goes to the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch.distributed as dist
     from multipitch_architectures_amd import nn_models, ops
@@ -383,12 +388,20 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    host_s = 0.0
     for _ in range(args.steps):
+        h0 = time.perf_counter()
         loss = step()
+        host_s += time.perf_counter() - h0        # what the host spends enqueueing one step (no synchronisation inside)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    host_ms = [host_s / args.steps * 1e3]
+    if world > 1:
+        hm = [None] * world
+        dist.all_gather_object(hm, host_ms[0])
+        host_ms = hm
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -454,6 +467,8 @@ def main():
                          "timed_in": "kernel-by-kernel steps right after the timed graph replays" if graphed
                                      else "the timed region"},
             "hip_graph": graphed,
+            "host_enqueue_ms_per_step": host_ms,      # per rank: host time to enqueue one step (graph replays + collectives)
+            "dp_graphs": bool(dp and graphed and train_step.graph_b is not None),
         }
         if args.config in TRAIN_GFLOP_PER_PATCH and args.frames == 75:     # the FLOP table is for T = 75 patches
             step_tflops = TRAIN_GFLOP_PER_PATCH[args.config] * patches_per_s / 1e3
@@ -470,7 +485,8 @@ def main():
             out["patch_extraction"] = patch_extraction_probe(B_loc, not args.no_cpu_baseline)
             out["eval_measures"] = eval_measures_probe(not args.no_cpu_baseline)
             out["segment_inference"] = segment_inference_probe(model)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dp:
         dist.destroy_process_group()
 

@@ -41,6 +41,10 @@ class GradientAverager:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.buckets = []        # list of dict(params, flat, views, pending, handle)
         self._owner = {}
+        # deferred: the hooks only gather a completed bucket into its flat buffer and leave the collective to
+        # launch_all() -- what `step.TrainStep` sets while it captures forward + backward as a HIP graph (no collective
+        # inside a captured graph; they run between the step's two graphs)
+        self.deferred = False
         # reverse registration order ~ order in which autograd produces gradients
         cur, cur_bytes = [], 0
         for p in reversed(self.params):
@@ -65,7 +69,8 @@ class GradientAverager:
         for p in plist:
             offs.append(off)
             off += p.numel()
-        b = {"params": plist, "flat": flat, "views": views, "pending": len(plist), "handle": None, "offsets": offs}
+        b = {"params": plist, "flat": flat, "views": views, "pending": len(plist), "handle": None, "offsets": offs,
+             "gathered": False}
         for p in plist:
             self._owner[p] = b
         self.buckets.append(b)
@@ -77,7 +82,8 @@ class GradientAverager:
             # the bucket is complete: gather its gradients into the flat buffer (one launch per 32 tensors instead of one
             # copy per parameter -- 168 of them for SAUnet:L) and put it on the wire
             self._gather(b)
-            if self.world > 1:
+            b["gathered"] = True
+            if self.world > 1 and not self.deferred:
                 b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     @staticmethod
@@ -101,25 +107,53 @@ class GradientAverager:
                                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         L.check(rc, "mpa_gather_copy")
 
-    def finish(self):
+    # finish() = gather_remaining() + launch_all() + wait_all() + scale_all() + expose(); the pieces are what the
+    # graph-captured step calls separately (gather inside the first graph, collectives between the graphs, scale inside
+    # the second one)
+    def gather_remaining(self):
+        """buckets that some parameter never reported to (no gradient this step): zeros for those, then gather"""
         for b in self.buckets:
-            if b["pending"] != 0:
-                # parameters that received no gradient this step contribute zeros
+            if b["pending"] != 0 and not b.get("gathered"):
                 for i, p in enumerate(b["params"]):
                     if p.grad is None:
                         b["views"][i].zero_()
                 self._gather(b)
-                if self.world > 1:
+                b["gathered"] = True
+
+    def launch_all(self):
+        """one asynchronous all-reduce per bucket that is not on the wire yet"""
+        if self.world > 1:
+            for b in self.buckets:
+                if b["handle"] is None:
                     b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def wait_all(self):
         for b in self.buckets:
             if b["handle"] is not None:
                 b["handle"].wait()
                 b["handle"] = None
-            if self.world > 1:
+
+    def scale_all(self):
+        if self.world > 1:
+            for b in self.buckets:
                 self._scale(b["flat"], 1.0 / self.world)
+
+    def expose(self):
+        """the averaged values become p.grad (views of the flat buffers); re-arm the buckets for the next step"""
+        for b in self.buckets:
             for p, v in zip(b["params"], b["views"]):
                 p.grad = v
             b["pending"] = len(b["params"])
+            b["gathered"] = False
+
+    def finish(self):
+        self.gather_remaining()
+        for b in self.buckets:
+            if b["handle"] is None and self.world > 1 and not self.deferred:
+                b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.wait_all()
+        self.scale_all()
+        self.expose()
 
     @staticmethod
     def _scale(flat, alpha):

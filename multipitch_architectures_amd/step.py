@@ -15,6 +15,13 @@ running statistics), so one capture serves the whole run.
         loss = step(x, y)                                 # static tensor; float(loss) syncs, as loss.item() does
 
 Batches whose shape differs from the captured one (the last, smaller batch of an epoch) run eagerly.
+
+Data-parallel ranks (an ``averager``) replay the step as *two* graphs with the collectives between them: graph A =
+forward + loss + backward + the gather of every gradient bucket into its flat buffer, then the bucketed RCCL all-reduces
+launched from the host, then graph B = 1/world scale + AdamW + dropout-stream advance.  No collective sits inside a
+captured graph, and a rank issues 2 graph launches + a handful of collectives per step instead of ~480 kernel launches
+-- which is what keeps eight ranks that share one host CPU off each other's critical path.  The all-reduce no longer
+overlaps the backward pass; for SAUnet:L that is 32.5 MB per step over xGMI (~0.4 ms) against a 28 ms step.
 """
 import os
 
@@ -26,9 +33,10 @@ from . import ops
 class TrainStep:
     def __init__(self, model, criterion, optimizer, averager=None, use_graph=True):
         self.model, self.criterion, self.opt, self.averager = model, criterion, optimizer, averager
-        # collectives stay outside captured graphs (see parallel.py): with an averager the step runs eagerly
-        self.use_graph = bool(use_graph) and averager is None
+        # collectives stay outside captured graphs (see parallel.py): with an averager the step is two graphs
+        self.use_graph = bool(use_graph)
         self.graph = None
+        self.graph_b = None          # data-parallel: scale + optimizer update (graph A = self.graph: forward + backward)
         self.shape = None            # shapes the graph was captured for
         self._eager_shape = None     # shapes of the last eager step (the capture follows an eager step of its shape)
         self._x = self._y = self._loss = None
@@ -39,8 +47,8 @@ class TrainStep:
         self._no_graph_shapes = set()   # shapes whose capture failed: they keep running kernel by kernel
         self._use_pack_tables = os.environ.get("MPA_PACK_TABLES", "1") != "0"      # diagnostics: "0" = pack bank by bank
 
-    # the loop body, launched kernel by kernel
-    def eager(self, x, y):
+    # the loop body in three phases (launched kernel by kernel, or captured: A = _fwd_bwd, B = _update)
+    def _fwd_bwd(self, x, y):
         # every filter bank this shape's step uses, re-packed for the current weights in one launch (the table is known
         # from the previous step of the shape; the first one packs lazily, bank by bank)
         shape = (tuple(x.shape), tuple(y.shape))
@@ -56,15 +64,28 @@ class TrainStep:
         loss = self.criterion(self.model(x), y)
         self.opt.zero_grad()
         loss.backward()
-        if self.averager is not None:
-            self.averager.finish()
+        return loss
+
+    def _update(self):
         self.opt.step()
+        ops.rng_advance()
+
+    def _bookkeep(self, shape):
+        tab = self._pack_tables.get(shape) if self._use_pack_tables else None
         keys = ops.pack_window_keys() if self._use_pack_tables else None
         if self._use_pack_tables and (tab is None or tab.keys != keys):
             if tab is not None:
                 self._old_tables.append(tab)         # a captured graph may still launch on it
             self._pack_tables[shape] = ops.build_pack_table(keys)
-        ops.rng_advance()
+
+    def eager(self, x, y):
+        capturing = torch.cuda.is_current_stream_capturing()
+        loss = self._fwd_bwd(x, y)
+        if self.averager is not None:
+            self.averager.finish()
+        self._update()
+        if not capturing:
+            self._bookkeep((tuple(x.shape), tuple(y.shape)))
         # detached: a caller holding the loss across iterations (every training loop does) must not keep this step's
         # autograd nodes alive -- stale AccumulateGrad nodes would run on the stream they were created on and break the
         # capture of the next step
@@ -79,15 +100,37 @@ class TrainStep:
         self.opt.zero_grad(set_to_none=True)
         graph = torch.cuda.CUDAGraph()
         rng_local = ops._Rng.local
+        av = self.averager
         try:
-            with torch.cuda.graph(graph):
-                self._loss = self.eager(self._x, self._y)
+            if av is None:
+                with torch.cuda.graph(graph):
+                    self._loss = self.eager(self._x, self._y)
+            else:
+                av.deferred = True                    # hooks gather into the flat buffers, no collective while capturing
+                try:
+                    with torch.cuda.graph(graph):
+                        self._loss = self._fwd_bwd(self._x, self._y).detach()
+                        av.gather_remaining()
+                finally:
+                    av.deferred = False
+                # a capture records, it does not run: nothing has been computed yet.  The update graph is captured right
+                # away (its inputs -- the flat buffers the gradients are averaged in -- have fixed addresses), and the
+                # caller replays both with the collectives in between.
+                av.expose()
+                graph_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_b, pool=graph.pool()):
+                    av.scale_all()
+                    self._update()
+                self.graph_b = graph_b
         except Exception:
             # nothing of the failed capture ran on the device; restore the host-side bookkeeping it touched and let the
             # caller run this shape kernel by kernel from now on
             ops._Rng.local = rng_local
             self._x = self._y = self._loss = None
-            self.graph = self.shape = None
+            self.graph = self.shape = self.graph_b = None
+            if av is not None:
+                for b in av.buckets:
+                    b["pending"], b["gathered"], b["handle"] = len(b["params"]), False, None
             self.opt.zero_grad(set_to_none=True)
             self.opt.invalidate_grad_table()
             raise
@@ -95,7 +138,7 @@ class TrainStep:
         self._opt_epoch = getattr(self.opt, "table_epoch", None)
 
     def _drop_graph(self):
-        self.graph = self.shape = None
+        self.graph = self.shape = self.graph_b = None
         self._x = self._y = self._loss = None
         self._eager_shape = None
         self._old_tables.clear()
@@ -130,6 +173,10 @@ class TrainStep:
             self._y.copy_(y)
         self.opt.sync_hyper()                        # ReduceLROnPlateau may have changed the learning rate
         self.graph.replay()
+        if self.averager is not None:                # collectives between the two graphs of a data-parallel step
+            self.averager.launch_all()
+            self.averager.wait_all()
+            self.graph_b.replay()
         self.replays += 1
         self.opt.note_steps(1)                       # host mirrors of what the graph did on the device
         self.opt.invalidate_grad_table()             # the replay left the graph's gradient addresses in the device table

@@ -7,6 +7,8 @@ grads: tiny:CNN (no BatchNorm, no batch-axis attention; eval mode switches dropo
        of the two half batches must equal the gradients of the full batch computed by the same HIP model.
 step : two data-parallel train steps of tiny:SAUnet (BN statistics and attention stay rank-local); parameters must stay
        bit-identical across the ranks.
+graph: the same loop through step.TrainStep with an averager: forward + backward and the update replayed as two HIP graphs
+       with the bucketed all-reduces between them; 5 steps, against the kernel-by-kernel data-parallel loop.
 """
 import json
 import os
@@ -62,6 +64,27 @@ def main():
             errs.append(max(float((p.grad - g).abs().max() / g.abs().max().clamp_min(1e-30))
                             for p, g in zip(model.parameters(), full)))
         out.update(buckets=len(avg.buckets), rel_err=max(errs))
+    elif case == "graph":
+        from multipitch_architectures_amd.step import TrainStep
+        runs = {}
+        for use_graph in (False, True):
+            model = build("tiny:SAUnet").train()
+            ops.manual_seed(11 + rank)
+            opt = AdamW(model.parameters(), lr=1e-3)
+            avg = GradientAverager(model.parameters(), bucket_bytes=1 << 16)
+            ts = TrainStep(model, BCELoss(), opt, averager=avg, use_graph=use_graph)
+            losses = [float(ts(x[lo:hi], y[lo:hi])) for _ in range(5)]
+            flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+            both = [torch.empty_like(flat) for _ in range(world)]
+            dist.all_gather(both, flat)
+            runs[use_graph] = dict(losses=losses, flat=flat, identical=all(bool(torch.equal(both[0], b)) for b in both[1:]),
+                                   replays=ts.replays, graphs=(ts.graph is not None, ts.graph_b is not None))
+            avg.remove()
+        a, b = runs[False]["flat"], runs[True]["flat"]
+        out.update(losses=runs[True]["losses"], losses_eager=runs[False]["losses"],
+                   params_identical=runs[True]["identical"] and runs[False]["identical"],
+                   finite=bool(torch.isfinite(b).all()), replays=runs[True]["replays"], graphs=runs[True]["graphs"],
+                   graph_vs_eager=float((a - b).abs().max() / a.abs().max()), opt_steps=int(next(iter(opt.state.values()))["step"]))
     else:
         model = build("tiny:SAUnet").train()
         ops.manual_seed(11 + rank)
