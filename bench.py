@@ -36,6 +36,10 @@ def parse_args(argv=None):
                     help="arithmetic of the 15-row convolutions: exact fp32-input MFMA (default, the headline) or the opt-in "
                     "split-bf16 path (hi*hi + hi*lo + lo*hi on bf16 MFMA, fp32 accumulation); the bf16x3 line carries "
                     "dtype 'bf16x3-f32acc' and its roofline against the bf16 MFMA peak / 3")
+    ap.add_argument("--sync-bn", action="store_true", help="data-parallel exactness mode: BatchNorm statistics over the global "
+                    "batch (all-reduce of the per-channel sums); the step then runs kernel by kernel")
+    ap.add_argument("--gather-attention", action="store_true", help="data-parallel exactness mode: the batch-axis attention "
+                    "sees the keys / values of every rank")
     ap.add_argument("--dp-rehearsal", action="store_true", help="with --gpus 1: run what a data-parallel rank runs (RCCL "
                     "process group of one rank, gradient hooks, bucketed asynchronous all-reduces, kernel-by-kernel "
                     "step) -- the per-rank cost of the data-parallel machinery on a one-GPU box; not a BASELINE line")
@@ -343,6 +347,7 @@ def main():
     x, y = x[lo:hi].to(dev), y[lo:hi].to(dev)               # inputs resident in HBM before the timed region
     ops.manual_seed(1234 + rank)
     ops.set_conv_precision(args.conv_precision)
+    ops.set_data_parallel_exactness(sync_bn=args.sync_bn, gather_attention=args.gather_attention)
     bfx = args.conv_precision == "bf16x3"
     peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if bfx else PEAK_FP32_MFMA_TFLOPS
 
@@ -469,6 +474,7 @@ def main():
             "hip_graph": graphed,
             "host_enqueue_ms_per_step": host_ms,      # per rank: host time to enqueue one step (graph replays + collectives)
             "dp_graphs": bool(dp and graphed and train_step.graph_b is not None),
+            "dp_exactness": {"sync_bn": bool(args.sync_bn), "gather_attention": bool(args.gather_attention)},
         }
         if args.config in TRAIN_GFLOP_PER_PATCH and args.frames == 75:     # the FLOP table is for T = 75 patches
             step_tflops = TRAIN_GFLOP_PER_PATCH[args.config] * patches_per_s / 1e3

@@ -143,6 +143,23 @@ int mpa_bn_relu_bwd(const float* dy, const float* x, const float* y /*nullable*/
                     float* dgamma, float* dbeta, double* stats_ws, int B, int C, int HW, int relu, int train,
                     void* stream);
 
+/* The training passes above in two halves with the per-channel sums handed to the caller in between (optional
+ * exactness mode "SyncBN"): a data-parallel rank all-reduces `sums` (2*C doubles: sum x, sum x^2 -- or sum g, sum g*xhat
+ * in backward) over the ranks and passes the *global* element count to the second half, so that an N x B/N run normalises
+ * with the statistics of the whole batch.  dgamma / dbeta of mpa_bn_relu_bwd_sums are this rank's share (the gradient
+ * averager sums them).  The ReLU mask is recomputed from x (beta must be given).                                 */
+int mpa_bn_batch_sums(const float* x, double* sums, int B, int C, int HW, void* stream);
+int mpa_bn_relu_train_fwd_sums(const float* x, const double* sums, double count, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, int64_t* num_batches_tracked, float* y,
+                               float* save_mean, float* save_invstd, int B, int C, int HW, float momentum, float eps, int relu,
+                               void* stream);
+int mpa_bn_relu_bwd_sums(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
+                         const float* save_invstd, double* stats, float* dgamma, float* dbeta, int B, int C, int HW, int relu,
+                         void* stream);
+int mpa_bn_relu_bwd_apply(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
+                          const float* save_invstd, const double* stats, double count, float* dx, int B, int C, int HW,
+                          int relu, void* stream);
+
 /* ------------------------------------------------------------------ pooling / upsampling
  * nn.MaxPool2d (unet_cnns.py:511-526; basic_cnns.py:376,393; unet_cnns.py:2314): -inf padding, floor mode.
  * idx holds the flat input offset (within the H*W plane) of each window's first maximum.              */
@@ -217,6 +234,14 @@ int mpa_attn_batchaxis_fwd(const float* q, const float* k, const float* v, float
 int mpa_attn_batchaxis_bwd(const float* q, const float* k, const float* v, const float* o, const float* lse,
                            const float* do_, float* dq, float* dk, float* dv, int B, int S, int E, int heads,
                            void* stream);
+
+/* Bq queries against Bk keys / values (k, v, dk, dv: (Bk,S,E); q, o, do, dq: (Bq,S,E); lse: (S,heads,Bq)): a data-parallel
+ * rank that has gathered the keys and values of all ranks attends over the whole batch (optional exactness mode) */
+int mpa_attn_batchaxis_fwd_kv(const float* q, const float* k, const float* v, float* o, float* lse, int Bq, int Bk, int S,
+                              int E, int heads, void* stream);
+int mpa_attn_batchaxis_bwd_kv(const float* q, const float* k, const float* v, const float* o, const float* lse,
+                              const float* do_, float* dq, float* dk, float* dv, int Bq, int Bk, int S, int E, int heads,
+                              void* stream);
 
 /* ------------------------------------------------------------------ LSTM cell (nn.LSTM, unet_cnns.py:232)
  * gates (B,4H) pre-activations in order i,f,g,o; c_prev nullable (zeros).                                  */

@@ -77,6 +77,12 @@ SIGNATURES = {
     "mpa_bn_relu_train_fwd_partials": (c_int, [_P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_int, _P]),
     "mpa_bn_relu_eval_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P]),
     "mpa_bn_relu_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "mpa_bn_batch_sums": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "mpa_bn_relu_train_fwd_sums": (c_int, [_P, _P, c_double, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_int, _P]),
+    "mpa_bn_relu_bwd_sums": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "mpa_bn_relu_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_double, _P, c_int, c_int, c_int, c_int, _P]),
+    "mpa_attn_batchaxis_fwd_kv": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "mpa_attn_batchaxis_bwd_kv": (c_int, [_P] * 9 + [c_int, c_int, c_int, c_int, c_int, _P]),
     "mpa_maxpool2d_fwd": (c_int, [_P, _P, _P] + [c_int] * 10 + [_P]),
     "mpa_maxpool2d_bwd": (c_int, [_P, _P, _P] + [c_int] * 10 + [_P]),
     "mpa_upcat_fwd": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P]),

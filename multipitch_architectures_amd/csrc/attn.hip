@@ -23,7 +23,9 @@ constexpr int QB = 64;       // own samples per workgroup
 template <int D>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                        const float* __restrict__ v, float* __restrict__ o,
-                                                       float* __restrict__ lse, int B, int S, int E, int heads, float scale) {
+                                                       float* __restrict__ lse, int B, int Bo, int S, int E, int heads,
+                                                       float scale) {
+  // B: queries (own samples, one per lane); Bo: keys / values (== B unless the keys of all data-parallel ranks were gathered)
   __shared__ float Ks[KC * D];
   __shared__ float Vs[KC * D];
   __shared__ float Ms[4][QB], Lsum[4][QB];
@@ -41,8 +43,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     acc[j] = 0.f;
   }
   float m = -INFINITY, l = 0.f;
-  for (int c0 = 0; c0 < B; c0 += KC) {
-    const int nk = min(KC, B - c0);
+  for (int c0 = 0; c0 < Bo; c0 += KC) {
+    const int nk = min(KC, Bo - c0);
     __syncthreads();
     for (int e = threadIdx.x; e < nk * D; e += 256) {
       const int kb = e / D, j = e - kb * D;
@@ -97,7 +99,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ v, const float* __restrict__ o,
                                                        const float* __restrict__ lse, const float* __restrict__ dO,
                                                        float* __restrict__ dq, float* __restrict__ dk,
-                                                       float* __restrict__ dv, int B, int S, int E, int heads, float scale) {
+                                                       float* __restrict__ dv, int B, int Bo, int BL, int S, int E, int heads,
+                                                       float scale) {
+  // B: own samples (queries in mode 0, keys in mode 1), Bo: the other axis, BL: number of queries (row length of lse)
   __shared__ float Xs[KC * D];      // mode 0: K chunk      mode 1: Q chunk
   __shared__ float Ys[KC * D];      // mode 0: V chunk      mode 1: dO chunk
   __shared__ float Ls[KC];          // mode 1: lse of the chunk's queries
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   const int d = E / heads;
   const long col0 = (long)s * E + h * d;
   const long rstride = (long)S * E;
-  const float* lrow = lse + ((long)s * heads + h) * B;
+  const float* lrow = lse + ((long)s * heads + h) * BL;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.z * QB + lane;
   const bool active = b < B;
@@ -128,8 +132,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     a1[j] = 0.f;
   }
   if (MODE == 0 && active) myl = lrow[b];
-  for (int c0 = 0; c0 < B; c0 += KC) {
-    const int nk = min(KC, B - c0);
+  for (int c0 = 0; c0 < Bo; c0 += KC) {
+    const int nk = min(KC, Bo - c0);
     __syncthreads();
     for (int e = threadIdx.x; e < nk * D; e += 256) {
       const int kb = e / D, j = e - kb * D;
@@ -191,49 +195,63 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
 }
 
 template <int D>
-void launch_attn_fwd(dim3 grid, hipStream_t st, const float* q, const float* k, const float* v, float* o, float* lse, int B,
-                     int S, int E, int heads, float scale) {
-  MPA_LAUNCH((attn_fwd_kernel<D>), grid, dim3(256), 0, st, q, k, v, o, lse, B, S, E, heads, scale);
+void launch_attn_fwd(dim3 grid, hipStream_t st, const float* q, const float* k, const float* v, float* o, float* lse, int Bq,
+                     int Bk, int S, int E, int heads, float scale) {
+  MPA_LAUNCH((attn_fwd_kernel<D>), grid, dim3(256), 0, st, q, k, v, o, lse, Bq, Bk, S, E, heads, scale);
 }
 template <int D>
 void launch_attn_bwd(dim3 grid, hipStream_t st, const float* q, const float* k, const float* v, const float* o,
-                     const float* lse, const float* dO, float* dq, float* dk, float* dv, int B, int S, int E, int heads,
-                     float scale) {
-  MPA_LAUNCH((attn_bwd_kernel<0, D>), grid, dim3(256), 0, st, q, k, v, o, lse, dO, dq, dk, dv, B, S, E, heads, scale);
-  MPA_LAUNCH((attn_bwd_kernel<1, D>), grid, dim3(256), 0, st, q, k, v, o, lse, dO, dq, dk, dv, B, S, E, heads, scale);
+                     const float* lse, const float* dO, float* dq, float* dk, float* dv, int Bq, int Bk, int S, int E,
+                     int heads, float scale) {
+  grid.z = (unsigned)mpa_cdiv(Bq, QB);
+  MPA_LAUNCH((attn_bwd_kernel<0, D>), grid, dim3(256), 0, st, q, k, v, o, lse, dO, dq, dk, dv, Bq, Bk, Bq, S, E, heads, scale);
+  grid.z = (unsigned)mpa_cdiv(Bk, QB);
+  MPA_LAUNCH((attn_bwd_kernel<1, D>), grid, dim3(256), 0, st, q, k, v, o, lse, dO, dq, dk, dv, Bk, Bq, Bq, S, E, heads, scale);
 }
 
 }  // namespace
 
 extern "C" {
 
-int mpa_attn_batchaxis_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B, int S, int E,
-                           int heads, void* stream) {
-  if (!q || !k || !v || !o || !lse || heads <= 0 || E % heads || E / heads > DMAX) return MPA_ERR_ARG;
+int mpa_attn_batchaxis_fwd_kv(const float* q, const float* k, const float* v, float* o, float* lse, int Bq, int Bk, int S,
+                              int E, int heads, void* stream) {
+  if (!q || !k || !v || !o || !lse || heads <= 0 || E % heads || E / heads > DMAX || Bq <= 0 || Bk <= 0) return MPA_ERR_ARG;
   const float scale = 1.0f / sqrtf((float)(E / heads));
   const int d = E / heads;
-  const dim3 grid(S, heads, (unsigned)mpa_cdiv(B, QB));
+  const dim3 grid(S, heads, (unsigned)mpa_cdiv(Bq, QB));
   hipStream_t st = (hipStream_t)stream;
-  if (d <= 4) launch_attn_fwd<4>(grid, st, q, k, v, o, lse, B, S, E, heads, scale);
-  else if (d <= 8) launch_attn_fwd<8>(grid, st, q, k, v, o, lse, B, S, E, heads, scale);
-  else if (d <= 16) launch_attn_fwd<16>(grid, st, q, k, v, o, lse, B, S, E, heads, scale);
-  else launch_attn_fwd<32>(grid, st, q, k, v, o, lse, B, S, E, heads, scale);
+  if (d <= 4) launch_attn_fwd<4>(grid, st, q, k, v, o, lse, Bq, Bk, S, E, heads, scale);
+  else if (d <= 8) launch_attn_fwd<8>(grid, st, q, k, v, o, lse, Bq, Bk, S, E, heads, scale);
+  else if (d <= 16) launch_attn_fwd<16>(grid, st, q, k, v, o, lse, Bq, Bk, S, E, heads, scale);
+  else launch_attn_fwd<32>(grid, st, q, k, v, o, lse, Bq, Bk, S, E, heads, scale);
   return mpa_launch_status();
 }
 
-int mpa_attn_batchaxis_bwd(const float* q, const float* k, const float* v, const float* o, const float* lse,
-                           const float* do_, float* dq, float* dk, float* dv, int B, int S, int E, int heads, void* stream) {
-  if (!q || !k || !v || !o || !lse || !do_ || !dq || !dk || !dv || heads <= 0 || E % heads || E / heads > DMAX)
+int mpa_attn_batchaxis_bwd_kv(const float* q, const float* k, const float* v, const float* o, const float* lse,
+                              const float* do_, float* dq, float* dk, float* dv, int Bq, int Bk, int S, int E, int heads,
+                              void* stream) {
+  if (!q || !k || !v || !o || !lse || !do_ || !dq || !dk || !dv || heads <= 0 || E % heads || E / heads > DMAX || Bq <= 0 ||
+      Bk <= 0)
     return MPA_ERR_ARG;
   const float scale = 1.0f / sqrtf((float)(E / heads));
   hipStream_t s = (hipStream_t)stream;
   const int d = E / heads;
-  const dim3 grid(S, heads, (unsigned)mpa_cdiv(B, QB));
-  if (d <= 4) launch_attn_bwd<4>(grid, s, q, k, v, o, lse, do_, dq, dk, dv, B, S, E, heads, scale);
-  else if (d <= 8) launch_attn_bwd<8>(grid, s, q, k, v, o, lse, do_, dq, dk, dv, B, S, E, heads, scale);
-  else if (d <= 16) launch_attn_bwd<16>(grid, s, q, k, v, o, lse, do_, dq, dk, dv, B, S, E, heads, scale);
-  else launch_attn_bwd<32>(grid, s, q, k, v, o, lse, do_, dq, dk, dv, B, S, E, heads, scale);
+  const dim3 grid(S, heads, 1);
+  if (d <= 4) launch_attn_bwd<4>(grid, s, q, k, v, o, lse, do_, dq, dk, dv, Bq, Bk, S, E, heads, scale);
+  else if (d <= 8) launch_attn_bwd<8>(grid, s, q, k, v, o, lse, do_, dq, dk, dv, Bq, Bk, S, E, heads, scale);
+  else if (d <= 16) launch_attn_bwd<16>(grid, s, q, k, v, o, lse, do_, dq, dk, dv, Bq, Bk, S, E, heads, scale);
+  else launch_attn_bwd<32>(grid, s, q, k, v, o, lse, do_, dq, dk, dv, Bq, Bk, S, E, heads, scale);
   return mpa_launch_status();
+}
+
+int mpa_attn_batchaxis_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B, int S, int E,
+                           int heads, void* stream) {
+  return mpa_attn_batchaxis_fwd_kv(q, k, v, o, lse, B, B, S, E, heads, stream);
+}
+
+int mpa_attn_batchaxis_bwd(const float* q, const float* k, const float* v, const float* o, const float* lse,
+                           const float* do_, float* dq, float* dk, float* dv, int B, int S, int E, int heads, void* stream) {
+  return mpa_attn_batchaxis_bwd_kv(q, k, v, o, lse, do_, dq, dk, dv, B, B, S, E, heads, stream);
 }
 
 }  // extern "C"

@@ -683,4 +683,61 @@ int mpa_bn_relu_bwd(const float* dy, const float* x, const float* y, const float
   return mpa_launch_status();
 }
 
+// ---- the same passes in two halves, with the per-channel sums handed to the caller in between: a data-parallel rank
+// all-reduces them over the ranks (SyncBN, SURVEY 8e's optional exactness mode) before the second half
+int mpa_bn_batch_sums(const float* x, double* sums, int B, int C, int HW, void* stream) {
+  if (!x || !sums || (long)B * HW > 0x7fffffffL) return MPA_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (mpa_zero_async(sums, sizeof(double) * 2 * C, s) != MPA_OK) return MPA_ERR_LAUNCH;
+  const int splits = stat_splits(B, C, HW);
+  const bool vec = HW % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  if (vec) MPA_LAUNCH(bn_stats_kernel<4>, dim3(splits, C), dim3(256), 0, s, x, sums, B, C, HW);
+  else MPA_LAUNCH(bn_stats_kernel<1>, dim3(splits, C), dim3(256), 0, s, x, sums, B, C, HW);
+  return mpa_launch_status();
+}
+
+int mpa_bn_relu_train_fwd_sums(const float* x, const double* sums, double count, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, int64_t* num_batches_tracked, float* y,
+                               float* save_mean, float* save_invstd, int B, int C, int HW, float momentum, float eps, int relu,
+                               void* stream) {
+  if (!x || !sums || !gamma || !beta || !running_mean || !running_var || !y || !save_mean || !save_invstd || count <= 0)
+    return MPA_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int chunks = (int)std::max<long>(1, std::min<long>(mpa_cdiv(HW, 1024), 64));
+  MPA_LAUNCH(bn_apply_kernel, dim3(B * C, chunks), dim3(256), 0, s, x, gamma, beta, sums, (const float*)nullptr,
+             (const float*)nullptr, y, C, HW, count, eps, relu);
+  MPA_LAUNCH(bn_finalize_kernel, dim3((unsigned)mpa_cdiv(C, 64)), dim3(64), 0, s, sums, running_mean, running_var,
+             num_batches_tracked, save_mean, save_invstd, C, count, momentum, eps);
+  return mpa_launch_status();
+}
+
+int mpa_bn_relu_bwd_sums(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
+                         const float* save_invstd, double* stats, float* dgamma, float* dbeta, int B, int C, int HW, int relu,
+                         void* stream) {
+  if (!dy || !x || !gamma || !beta || !save_mean || !save_invstd || !stats || !dgamma || !dbeta || (long)B * HW > 0x7fffffffL)
+    return MPA_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (mpa_zero_async(stats, sizeof(double) * 2 * C, s) != MPA_OK) return MPA_ERR_LAUNCH;
+  const int splits = stat_splits(B, C, HW);
+  const bool vec = HW % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+  if (vec) MPA_LAUNCH(bn_bwd_stats_kernel<4>, dim3(splits, C), dim3(256), 0, s, dy, x, x, gamma, beta, save_mean, save_invstd,
+                      stats, B, C, HW, relu);
+  else MPA_LAUNCH(bn_bwd_stats_kernel<1>, dim3(splits, C), dim3(256), 0, s, dy, x, x, gamma, beta, save_mean, save_invstd, stats,
+                  B, C, HW, relu);
+  // this rank's parameter gradients come from its own sums (the gradient averager sums them over the ranks)
+  MPA_LAUNCH(bn_bwd_finalize_kernel, dim3((unsigned)mpa_cdiv(C, 64)), dim3(64), 0, s, (const double*)stats, dgamma, dbeta, C);
+  return mpa_launch_status();
+}
+
+int mpa_bn_relu_bwd_apply(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
+                          const float* save_invstd, const double* stats, double count, float* dx, int B, int C, int HW,
+                          int relu, void* stream) {
+  if (!dy || !x || !gamma || !beta || !save_mean || !save_invstd || !stats || !dx || count <= 0) return MPA_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int chunks = (int)std::max<long>(1, std::min<long>(mpa_cdiv(HW, 1024), 64));
+  MPA_LAUNCH(bn_bwd_apply_kernel, dim3(B * C, chunks), dim3(256), 0, s, dy, x, x, gamma, beta, save_mean, save_invstd, stats,
+             dx, C, HW, count, relu, 1);
+  return mpa_launch_status();
+}
+
 }  // extern "C"

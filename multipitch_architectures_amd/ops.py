@@ -206,6 +206,34 @@ def run_pack_table(tab):
         _pack_cache[wid] = (weakref.ref(w), sig, {k: _pack_buffers[(wid, k)][1] for k in keys})
 
 
+# --------------------------------------------------------------------------- data-parallel exactness modes
+class _Sync:
+    bn = False            # BatchNorm statistics over the *global* batch: all-reduce of 2*C sums per layer and direction
+    attn = False          # batch-axis attention over the *global* batch: all-gather of K and V, reduce of dK and dV
+    group = None
+
+
+def set_data_parallel_exactness(sync_bn=False, gather_attention=False, group=None):
+    """By default a data-parallel rank normalises and attends over its local shard (what DistributedDataParallel around
+    the reference would do), so an N x B/N run computes a slightly different model than the 1 x B run.  With these modes
+    on, train-mode BatchNorm uses the statistics of the whole batch (SyncBN: the per-channel sums are all-reduced between
+    the two halves of each pass) and the batch-axis attention sees the keys / values of every rank -- an N x B/N run then
+    reproduces the 1 x B run's loss and gradients to fp32 rounding.  Both put collectives inside forward / backward:
+    `step.TrainStep` launches such steps kernel by kernel (no HIP graph)."""
+    _Sync.bn, _Sync.attn, _Sync.group = bool(sync_bn), bool(gather_attention), group
+
+
+def _dp_world():
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    return dist.get_world_size(_Sync.group)
+
+
+def exactness_collectives_active():
+    return (_Sync.bn or _Sync.attn) and _dp_world() > 1
+
+
 # --------------------------------------------------------------------------- split-bf16 ("bf16x3") convolution path
 class _Precision:
     conv = "f32"          # "f32": exact fp32-input MFMA (default, the headline) | "bf16x3": hi/lo bf16 split, 3 MFMAs, fp32 acc
@@ -511,7 +539,21 @@ class BatchNormReLUFn(torch.autograd.Function):
         save_mean = torch.empty(C, dtype=torch.float32, device=x.device)
         save_invstd = torch.empty_like(save_mean)
         lib = _lib()
-        if training and partials is not None:
+        ctx.sync_world = 1
+        if training and _Sync.bn and _dp_world() > 1:
+            # SyncBN: this rank's sums, all-reduced, then normalisation with the global count (equal shards)
+            import torch.distributed as dist
+            world = _dp_world()
+            sums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+            _chk(lib.mpa_bn_batch_sums(_p(x), ctypes.c_void_p(sums.data_ptr()), B, C, H * W, _s()), "mpa_bn_batch_sums")
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=_Sync.group)
+            _chk(lib.mpa_bn_relu_train_fwd_sums(_p(x), ctypes.c_void_p(sums.data_ptr()), float(B * H * W * world), _p(gamma),
+                                               _p(beta), _p(running_mean), _p(running_var),
+                                               ctypes.c_void_p(nbt.data_ptr()) if nbt is not None else None, _p(y),
+                                               _p(save_mean), _p(save_invstd), B, C, H * W, float(momentum), BN_EPS,
+                                               int(relu), _s()), "mpa_bn_relu_train_fwd_sums")
+            ctx.sync_world = world
+        elif training and partials is not None:
             # batch statistics from the producing convolution's epilogue: no statistics pass over x
             if partials.shape[1:] != (C, 2):
                 raise RuntimeError(f"batchnorm: partial sums of shape {tuple(partials.shape)} for {C} channels")
@@ -546,6 +588,17 @@ class BatchNormReLUFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         ws = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+        if ctx.training and ctx.sync_world > 1:
+            import torch.distributed as dist
+            lib = _lib()
+            _chk(lib.mpa_bn_relu_bwd_sums(_p(dy), _p(x), _p(gamma), _p(beta), _p(save_mean), _p(save_invstd),
+                                         ctypes.c_void_p(ws.data_ptr()), _p(dgamma), _p(dbeta), B, C, H * W, int(ctx.relu),
+                                         _s()), "mpa_bn_relu_bwd_sums")
+            dist.all_reduce(ws, op=dist.ReduceOp.SUM, group=_Sync.group)
+            _chk(lib.mpa_bn_relu_bwd_apply(_p(dy), _p(x), _p(gamma), _p(beta), _p(save_mean), _p(save_invstd),
+                                          ctypes.c_void_p(ws.data_ptr()), float(B * H * W * ctx.sync_world), _p(dx), B, C,
+                                          H * W, int(ctx.relu), _s()), "mpa_bn_relu_bwd_apply")
+            return dx, dgamma, dbeta, None, None, None, None, None, None, None
         _chk(_lib().mpa_bn_relu_bwd(_p(dy), _p(x), None, _p(gamma), _p(beta), _p(save_mean), _p(save_invstd), _p(dx), _p(dgamma),
                                    _p(dbeta), ctypes.c_void_p(ws.data_ptr()), B, C, H * W, int(ctx.relu),
                                    int(ctx.training), _s()), "mpa_bn_relu_bwd")
@@ -943,17 +996,28 @@ class InProjFn(torch.autograd.Function):
 
 
 class AttnBatchAxisFn(torch.autograd.Function):
-    """softmax(q k^T / sqrt(d)) v over the batch axis for every position and head (Appendix C.1)."""
+    """softmax(q k^T / sqrt(d)) v over the batch axis for every position and head (Appendix C.1).  With
+    `set_data_parallel_exactness(gather_attention=True)` on a data-parallel rank the keys and values of all ranks are
+    gathered first (rank-major = the order of the global batch), and the backward pass sums the key / value gradients over
+    the ranks and keeps this rank's slice."""
 
     @staticmethod
     def forward(ctx, q, k, v, heads):
         q, k, v = _c(q), _c(k), _c(v)
         B, S, E = q.shape
+        world = _dp_world() if _Sync.attn else 1
+        if world > 1:
+            import torch.distributed as dist
+            k_all = torch.empty((world * B, S, E), dtype=torch.float32, device=q.device)
+            v_all = torch.empty_like(k_all)
+            dist.all_gather(list(k_all.chunk(world)), k, group=_Sync.group)      # rank-major = global batch order
+            dist.all_gather(list(v_all.chunk(world)), v, group=_Sync.group)
+            k, v = k_all, v_all
         o = torch.empty_like(q)
         lse = torch.empty((S, heads, B), dtype=torch.float32, device=q.device)
-        _chk(_lib().mpa_attn_batchaxis_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), B, S, E, heads, _s()),
-             "mpa_attn_batchaxis_fwd")
-        ctx.heads = heads
+        _chk(_lib().mpa_attn_batchaxis_fwd_kv(_p(q), _p(k), _p(v), _p(o), _p(lse), B, k.shape[0], S, E, heads, _s()),
+             "mpa_attn_batchaxis_fwd_kv")
+        ctx.heads, ctx.world = heads, world
         ctx.save_for_backward(q, k, v, o, lse)
         return o
 
@@ -962,9 +1026,15 @@ class AttnBatchAxisFn(torch.autograd.Function):
         q, k, v, o, lse = ctx.saved_tensors
         do = _c(do)
         B, S, E = q.shape
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
-        _chk(_lib().mpa_attn_batchaxis_bwd(_p(q), _p(k), _p(v), _p(o), _p(lse), _p(do), _p(dq), _p(dk), _p(dv), B, S, E,
-                                          ctx.heads, _s()), "mpa_attn_batchaxis_bwd")
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(k)
+        _chk(_lib().mpa_attn_batchaxis_bwd_kv(_p(q), _p(k), _p(v), _p(o), _p(lse), _p(do), _p(dq), _p(dk), _p(dv), B,
+                                             k.shape[0], S, E, ctx.heads, _s()), "mpa_attn_batchaxis_bwd_kv")
+        if ctx.world > 1:
+            import torch.distributed as dist
+            rank = dist.get_rank(_Sync.group)
+            dist.all_reduce(dk, op=dist.ReduceOp.SUM, group=_Sync.group)
+            dist.all_reduce(dv, op=dist.ReduceOp.SUM, group=_Sync.group)
+            dk, dv = dk[rank * B:(rank + 1) * B].contiguous(), dv[rank * B:(rank + 1) * B].contiguous()
         return dq, dk, dv, None
 
 

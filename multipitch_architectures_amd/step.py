@@ -144,7 +144,8 @@ class TrainStep:
         self._old_tables.clear()
 
     def __call__(self, x, y):
-        if not self.use_graph or not self.model.training:
+        if not self.use_graph or not self.model.training or ops.exactness_collectives_active():
+            # (SyncBN / gathered attention put collectives inside forward and backward: never captured)
             # the captured graph is the *training* step (dropout, batch statistics, running-stat updates): after
             # model.eval() the loop body runs kernel by kernel with whatever mode the modules are in
             return self.eager(x, y)

@@ -64,11 +64,44 @@ def main():
             errs.append(max(float((p.grad - g).abs().max() / g.abs().max().clamp_min(1e-30))
                             for p, g in zip(model.parameters(), full)))
         out.update(buckets=len(avg.buckets), rel_err=max(errs))
+    elif case == "exact":
+        # SURVEY 8e exactness modes: with SyncBN and gathered keys / values a 2 x B/2 run reproduces the 1 x B run
+        from multipitch_architectures_amd.nn_models.layers import Dropout
+        model = build("tiny:SAUnet").train()
+        for m in model.modules():
+            if isinstance(m, Dropout):
+                m.p = 0.0
+            if hasattr(m, "p_dropout"):
+                m.p_dropout = 0.0
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        full_loss = BCELoss()(model(x), y)
+        full_loss.backward()
+        full = [p.grad.clone() for p in model.parameters()]
+        model.load_state_dict(sd0)                       # (running statistics moved: restore)
+        model.zero_grad(set_to_none=True)
+        res = {}
+        for mode in ("local", "exact"):
+            ops.set_data_parallel_exactness(sync_bn=mode == "exact", gather_attention=mode == "exact")
+            model.load_state_dict(sd0)
+            model.zero_grad(set_to_none=True)
+            avg = GradientAverager(model.parameters(), bucket_bytes=1 << 16)
+            loss = BCELoss()(model(x[lo:hi]), y[lo:hi])
+            loss.backward()
+            avg.finish()
+            lsum = loss.detach().clone()
+            dist.all_reduce(lsum)
+            errs = [float((p.grad - g).abs().max() / g.abs().max().clamp_min(1e-30)) for p, g in zip(model.parameters(), full)
+                    if float(g.abs().max()) > 1e-6]
+            res[mode] = dict(loss_err=abs(float(lsum) / world - float(full_loss)), grad_err=max(errs),
+                             grad_err_median=sorted(errs)[len(errs) // 2])
+            avg.remove()
+        ops.set_data_parallel_exactness()
+        rm = [v for k, v in model.state_dict().items() if k.endswith("running_mean")][0]
+        out.update(res=res, full_loss=float(full_loss))
     elif case == "graph":
         from multipitch_architectures_amd.step import TrainStep
-        runs = {}
-        for use_graph in (False, True):
-            model = build("tiny:SAUnet").train()
+        def run(name, use_graph):
+            model = build(name).train()
             ops.manual_seed(11 + rank)
             opt = AdamW(model.parameters(), lr=1e-3)
             avg = GradientAverager(model.parameters(), bucket_bytes=1 << 16)
@@ -77,14 +110,20 @@ def main():
             flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
             both = [torch.empty_like(flat) for _ in range(world)]
             dist.all_gather(both, flat)
-            runs[use_graph] = dict(losses=losses, flat=flat, identical=all(bool(torch.equal(both[0], b)) for b in both[1:]),
-                                   replays=ts.replays, graphs=(ts.graph is not None, ts.graph_b is not None))
             avg.remove()
+            return dict(losses=losses, flat=flat, identical=all(bool(torch.equal(both[0], b)) for b in both[1:]),
+                        replays=ts.replays, graphs=(ts.graph is not None, ts.graph_b is not None),
+                        opt_steps=int(next(iter(opt.state.values()))["step"]))
+        runs = {g: run("tiny:SAUnet", g) for g in (False, True)}
+        cnn = {g: run("tiny:CNN", g) for g in (False, True)}
         a, b = runs[False]["flat"], runs[True]["flat"]
+        ca, cb = cnn[False]["flat"], cnn[True]["flat"]
         out.update(losses=runs[True]["losses"], losses_eager=runs[False]["losses"],
-                   params_identical=runs[True]["identical"] and runs[False]["identical"],
+                   params_identical=runs[True]["identical"] and runs[False]["identical"] and cnn[True]["identical"],
                    finite=bool(torch.isfinite(b).all()), replays=runs[True]["replays"], graphs=runs[True]["graphs"],
-                   graph_vs_eager=float((a - b).abs().max() / a.abs().max()), opt_steps=int(next(iter(opt.state.values()))["step"]))
+                   graph_vs_eager=float((a - b).abs().max() / a.abs().max()), opt_steps=runs[True]["opt_steps"],
+                   cnn_graph_vs_eager=float((ca - cb).abs().max() / ca.abs().max()),
+                   cnn_loss_dev=max(abs(u - v) for u, v in zip(cnn[True]["losses"], cnn[False]["losses"])))
     else:
         model = build("tiny:SAUnet").train()
         ops.manual_seed(11 + rank)
