@@ -85,3 +85,17 @@ TRAIN_GFLOP_PER_PATCH = {"DRCNN:L": 436.32, "Unet:L": 88.25, "SAUnet:L": 86.67, 
                          "PUnet:XL": 243.93}
 FWD_GMAC_PER_PATCH = {"CNN:XS": 0.458, "DRCNN:L": 73.230, "Unet:L": 14.825, "SAUnet:L": 14.562,
                       "BLUnet:XXL": 15.285, "PUnet:XL": 40.888}
+
+# tiny instances of the U-Net variants no experiment uses (oracle/make_goldens_variants.py, tests/test_gpu_variants.py)
+_VT = dict(n_chan_layers=[8, 6, 5, 4], n_bins_out=72, scalefac=16)
+_VA = dict(embed_dim=32, num_heads=4, mlp_dim=24)
+VARIANT_CONFIGS = {
+    "simple_u_net": dict(_VT),
+    "simple_u_net_selfattn": dict(_VT, **_VA),
+    "simple_u_net_sixselfattn": dict(_VT, **_VA, pos_encoding="sinusoidal"),
+    "simple_u_net_doubleselfattn_alllayers": dict(_VT, **_VA),
+    "simple_u_net_doubleselfattn_varlayers": dict(_VT, **_VA, self_attn_depth=2, self_attn_number=2, pos_encoding="sinusoidal"),
+    "simple_u_net_polyphony_classif": dict(_VT, num_polyphony_steps=24),
+    "simple_u_net_doubleselfattn_polyphony": dict(_VT, **_VA),
+    "simple_u_net_doubleselfattn_polyphony_classif": dict(_VT, **_VA, num_polyphony_steps=24),
+}

@@ -196,25 +196,30 @@ class blstm_temporal_enc_layer(nn.Module):
 class _UNetTrunk(nn.Module):
     """Layers shared by simple_u_net_largekernels and its descendants (unet_cnns.py:345-393)."""
 
+    # kernel size per level, top (75x216) to bottom: the large-kernel family; simple_u_net uses 3 everywhere
+    LARGE = (15, 15, 9, 5, 3)
+
     def _build_trunk(self, n_in, n_ch, n_bins_in, n_bins_out, a_lrelu, p_dropout, sc, convdrop=0, residual=False,
-                     alt_order=False, inc_alt_order=False):
+                     alt_order=False, inc_alt_order=False, ks=LARGE):
         self.layernorm = LayerNorm(normalized_shape=[n_in, n_bins_in])
         kw = dict(convdrop=convdrop, residual=residual, alt_order=alt_order)
-        self.inc = double_conv(in_channels=n_in, mid_channels=64 // sc, out_channels=64 // sc, kernel_size=(15, 15),
-                               padding=(7, 7), convdrop=convdrop, alt_order=inc_alt_order)
-        self.down1 = nn.Sequential(MaxPool2d((2, 2)), double_conv(in_channels=64 // sc, out_channels=128 // sc, mid_channels=128 // sc, kernel_size=(15, 15), padding=(7, 7), **kw))
-        self.down2 = nn.Sequential(MaxPool2d((2, 2)), double_conv(in_channels=128 // sc, out_channels=256 // sc, mid_channels=256 // sc, kernel_size=(9, 9), padding=(4, 4), **kw))
-        self.down3 = nn.Sequential(MaxPool2d((2, 2)), double_conv(in_channels=256 // sc, out_channels=512 // sc, mid_channels=512 // sc, kernel_size=(5, 5), padding=(2, 2), **kw))
-        self.down4 = nn.Sequential(MaxPool2d((2, 2)), double_conv(in_channels=512 // sc, out_channels=1024 // (sc * 2), mid_channels=1024 // (sc * 2), kernel_size=(3, 3), padding=(1, 1), **kw))
+        kp = lambda k: dict(kernel_size=(k, k), padding=(k // 2, k // 2))
+        self.inc = double_conv(in_channels=n_in, mid_channels=64 // sc, out_channels=64 // sc, convdrop=convdrop,
+                               alt_order=inc_alt_order, **kp(ks[0]))
+        self.down1 = nn.Sequential(MaxPool2d((2, 2)), double_conv(in_channels=64 // sc, out_channels=128 // sc, mid_channels=128 // sc, **kp(ks[1]), **kw))
+        self.down2 = nn.Sequential(MaxPool2d((2, 2)), double_conv(in_channels=128 // sc, out_channels=256 // sc, mid_channels=256 // sc, **kp(ks[2]), **kw))
+        self.down3 = nn.Sequential(MaxPool2d((2, 2)), double_conv(in_channels=256 // sc, out_channels=512 // sc, mid_channels=512 // sc, **kp(ks[3]), **kw))
+        self.down4 = nn.Sequential(MaxPool2d((2, 2)), double_conv(in_channels=512 // sc, out_channels=1024 // (sc * 2), mid_channels=1024 // (sc * 2), **kp(ks[4]), **kw))
 
     def _build_decoder(self, n_ch, n_bins_in, n_bins_out, a_lrelu, p_dropout, sc, convdrop=0, residual=False,
-                       alt_order=False):
+                       alt_order=False, ks=LARGE):
         kw = dict(convdrop=convdrop, residual=residual, alt_order=alt_order)
+        kp = lambda k: dict(kernel_size=(k, k), padding=(k // 2, k // 2))
         self.upconcat = unet_up_concat_padding((2, 2))
-        self.upconv1 = double_conv(in_channels=1024 // sc, out_channels=512 // (sc * 2), mid_channels=1024 // (sc * 2), kernel_size=(3, 3), padding=(1, 1), **kw)
-        self.upconv2 = double_conv(in_channels=512 // sc, out_channels=256 // (sc * 2), mid_channels=512 // (sc * 2), kernel_size=(5, 5), padding=(2, 2), **kw)
-        self.upconv3 = double_conv(in_channels=256 // sc, out_channels=128 // (sc * 2), mid_channels=256 // (sc * 2), kernel_size=(9, 9), padding=(4, 4), **kw)
-        self.upconv4 = double_conv(in_channels=128 // sc, out_channels=n_ch[0], mid_channels=128 // (sc * 2), kernel_size=(15, 15), padding=(7, 7), **kw)
+        self.upconv1 = double_conv(in_channels=1024 // sc, out_channels=512 // (sc * 2), mid_channels=1024 // (sc * 2), **kp(ks[4]), **kw)
+        self.upconv2 = double_conv(in_channels=512 // sc, out_channels=256 // (sc * 2), mid_channels=512 // (sc * 2), **kp(ks[3]), **kw)
+        self.upconv3 = double_conv(in_channels=256 // sc, out_channels=128 // (sc * 2), mid_channels=256 // (sc * 2), **kp(ks[2]), **kw)
+        self.upconv4 = double_conv(in_channels=128 // sc, out_channels=n_ch[0], mid_channels=128 // (sc * 2), **kp(ks[0]), **kw)
         self.conv2, self.conv3, self.conv4 = _head(n_ch[0], n_ch, n_bins_in, n_bins_out, a_lrelu, p_dropout)
 
     def _encode(self, x):
@@ -362,3 +367,180 @@ class simple_u_net_polyphony_classif_softmax(_UNetTrunk):
         y_pred = self._decode(x1, x2, x3, x4, x5)
         n_pred = self.convP(x5)
         return y_pred, n_pred
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Variants the reference exports but no experiment script instantiates: re-compositions of the
+# blocks above, kept drop-in (constructor signatures, attribute names = state_dict keys, forward order).  Parity:
+# tests/golden/xcls-*.npz, produced by the reference classes themselves (oracle/make_goldens_variants.py).
+
+class simple_u_net(_UNetTrunk):
+    """unet_cnns.py:251-330: the U-Net with 3x3 kernels on every level."""
+
+    def __init__(self, n_chan_input=6, n_chan_layers=[64, 30, 20, 10], n_bins_in=216,
+                 n_bins_out=12, a_lrelu=0.3, p_dropout=0.2, scalefac=8):
+        super().__init__()
+        ks = (3, 3, 3, 3, 3)
+        self._build_trunk(n_chan_input, n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, scalefac, ks=ks)
+        self._build_decoder(n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, scalefac, ks=ks)
+
+    def forward(self, x):
+        return self._decode(*self._encode(x))
+
+
+class simple_u_net_selfattn(_UNetTrunk):
+    """unet_cnns.py:415-492: one transformer encoder layer on the bottleneck."""
+
+    def __init__(self, n_chan_input=6, n_chan_layers=[64, 30, 20, 10], n_bins_in=216, n_bins_out=12,
+                 a_lrelu=0.3, p_dropout=0.2, scalefac=16, embed_dim=4 * 8, num_heads=8, mlp_dim=512):
+        super().__init__()
+        self._build_trunk(n_chan_input, n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, scalefac)
+        self.attention = transformer_enc_layer(embed_dim=embed_dim, num_heads=num_heads, mlp_dim=mlp_dim)    # :447
+        self._build_decoder(n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, scalefac)
+
+    def forward(self, x):
+        x1, x2, x3, x4, x5 = self._encode(x)
+        return self._decode(x1, x2, x3, x4, self.attention(x5))
+
+
+class simple_u_net_sixselfattn(_UNetTrunk):
+    """unet_cnns.py:579-666: six transformer encoder layers on the bottleneck (class-default dropout, :611-616)."""
+
+    def __init__(self, n_chan_input=6, n_chan_layers=[64, 30, 20, 10], n_bins_in=216, n_bins_out=12,
+                 a_lrelu=0.3, p_dropout=0.2, scalefac=16, embed_dim=4 * 8, num_heads=8, mlp_dim=512, pos_encoding=None):
+        super().__init__()
+        self._build_trunk(n_chan_input, n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, scalefac)
+        self.attention1 = transformer_enc_layer(embed_dim=embed_dim, num_heads=num_heads, mlp_dim=mlp_dim, pos_encoding=pos_encoding)
+        for i in range(2, 7):
+            setattr(self, f"attention{i}", transformer_enc_layer(embed_dim=embed_dim, num_heads=num_heads, mlp_dim=mlp_dim))
+        self._build_decoder(n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, scalefac)
+
+    def forward(self, x):
+        x1, x2, x3, x4, x5 = self._encode(x)
+        for i in range(1, 7):
+            x5 = getattr(self, f"attention{i}")(x5)
+        return self._decode(x1, x2, x3, x4, x5)
+
+
+class simple_u_net_doubleselfattn_varlayers(_UNetTrunk):
+    """unet_cnns.py:863-996: `self_attn_number` (0..2) transformer encoder layers on the bottleneck and on the skip
+    connections of the deepest `self_attn_depth` levels (embed_dim, embed_dim, /2, /4, /8 channels)."""
+
+    def __init__(self, n_chan_input=6, n_chan_layers=[64, 30, 20, 10], n_bins_in=216, n_bins_out=12, a_lrelu=0.3,
+                 p_dropout=0.2, scalefac=8, embed_dim=4 * 16, num_heads=8, mlp_dim=512, self_attn_depth=0,
+                 self_attn_number=2, pos_encoding=None):
+        super().__init__()
+        self.attn_depth = self_attn_depth
+        self.attn_number = self_attn_number
+        self._build_trunk(n_chan_input, n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, scalefac)
+        self._attn_layers(embed_dim, num_heads, mlp_dim, p_dropout, pos_encoding, self_attn_depth, self_attn_number)
+        self._build_decoder(n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, scalefac)
+
+    def _attn_layers(self, embed_dim, num_heads, mlp_dim, p_dropout, pos_encoding, depth, number):
+        for lvl, (level, div) in enumerate(((5, 1), (4, 1), (3, 2), (2, 4), (1, 8))):
+            if depth > lvl:
+                if number > 0:
+                    setattr(self, f"attention{level}a", transformer_enc_layer(embed_dim=embed_dim // div, num_heads=num_heads, mlp_dim=mlp_dim, p_dropout=p_dropout, pos_encoding=pos_encoding))
+                if number > 1:
+                    setattr(self, f"attention{level}b", transformer_enc_layer(embed_dim=embed_dim // div, num_heads=num_heads, mlp_dim=mlp_dim, p_dropout=p_dropout))
+
+    def _attend(self, t, level, lvl):
+        if self.attn_depth > lvl:
+            if self.attn_number > 0:
+                t = getattr(self, f"attention{level}a")(t)
+            if self.attn_number > 1:
+                t = getattr(self, f"attention{level}b")(t)
+        return t
+
+    def forward(self, x):
+        x1, x2, x3, x4, x5 = self._encode(x)
+        x5 = self._attend(x5, 5, 0)
+        x4 = self._attend(x4, 4, 1)
+        x = self.upconv1(self.upconcat(x5, x4))
+        x3 = self._attend(x3, 3, 2)
+        x = self.upconv2(self.upconcat(x, x3))
+        x2 = self._attend(x2, 2, 3)
+        x = self.upconv3(self.upconcat(x, x2))
+        x1 = self._attend(x1, 1, 4)
+        x = self.upconv4(self.upconcat(x, x1))
+        return self.conv4(self.conv3(self.conv2(x)))
+
+
+class simple_u_net_doubleselfattn_alllayers(simple_u_net_doubleselfattn_varlayers):
+    """unet_cnns.py:758-860: two transformer encoder layers on the bottleneck and on every skip connection."""
+
+    def __init__(self, n_chan_input=6, n_chan_layers=[64, 30, 20, 10], n_bins_in=216, n_bins_out=12,
+                 a_lrelu=0.3, p_dropout=0.2, scalefac=8, embed_dim=4 * 16, num_heads=8, mlp_dim=512):
+        _UNetTrunk.__init__(self)
+        self.attn_depth, self.attn_number = 5, 2
+        self._build_trunk(n_chan_input, n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, scalefac)
+        self._attn_layers(embed_dim, num_heads, mlp_dim, p_dropout, None, 5, 2)
+        self._build_decoder(n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, scalefac)
+
+
+class _PolyHeadReLU(nn.Sequential):
+    """convP of the regression / classification variants: as _PolyHead with a final ReLU (unet_cnns.py:2040-2047)."""
+
+    def forward(self, x):
+        conv_a, act, pool, drop, conv_b, _relu = list(self)
+        return conv_b(drop(pool(conv_a(x, act.act, act.slope))), ops.ACT_RELU)
+
+
+def _conv_p(c_in, c_mid, c_out, a_lrelu, p_dropout):
+    return _PolyHeadReLU(
+        Conv2d(c_in, c_mid, kernel_size=(2, 5), padding=(0, 0), stride=(1, 1)), LeakyReLU(negative_slope=a_lrelu),
+        MaxPool2d(kernel_size=(2, 5), stride=(1, 2), padding=(0, 0)), Dropout(p=p_dropout),
+        Conv2d(c_mid, c_out, kernel_size=(2, 3), padding=(0, 0), stride=(1, 1)), ReLU())
+
+
+class simple_u_net_polyphony_classif(_UNetTrunk):
+    """unet_cnns.py:2163-2248: degree-of-polyphony head (ReLU output) on the bottleneck; returns (y_pred, n_pred)."""
+
+    def __init__(self, n_chan_input=6, n_chan_layers=[64, 30, 20, 10], n_bins_in=216, n_bins_out=12,
+                 a_lrelu=0.3, p_dropout=0.2, scalefac=16, num_polyphony_steps=24):
+        super().__init__()
+        sc = scalefac
+        self._build_trunk(n_chan_input, n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, sc)
+        self._build_decoder(n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, sc)
+        self.convP = _conv_p(1024 // (sc * 2), 1024 // (sc * 4), num_polyphony_steps, a_lrelu, p_dropout)
+
+    def forward(self, x):
+        x1, x2, x3, x4, x5 = self._encode(x)
+        return self._decode(x1, x2, x3, x4, x5), self.convP(x5)
+
+
+class _SAUnetPoly(_UNetTrunk):
+    def _build(self, n_chan_input, n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, scalefac, embed_dim, num_heads,
+               mlp_dim, pos_encoding, poly_mid, poly_out):
+        self._build_trunk(n_chan_input, n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, scalefac)
+        self.attention1 = transformer_enc_layer(embed_dim=embed_dim, num_heads=num_heads, mlp_dim=mlp_dim, pos_encoding=pos_encoding)
+        self.attention2 = transformer_enc_layer(embed_dim=embed_dim, num_heads=num_heads, mlp_dim=mlp_dim)
+        self._build_decoder(n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, scalefac)
+        self.convP = _conv_p(embed_dim, poly_mid, poly_out, a_lrelu, p_dropout)
+
+    def forward(self, x):
+        x1, x2, x3, x4, x5 = self._encode(x)
+        x5_inner = self.attention1(x5)
+        x5 = self.attention2(x5_inner)
+        return self._decode(x1, x2, x3, x4, x5), self.convP(x5_inner)
+
+
+class simple_u_net_doubleselfattn_polyphony(_SAUnetPoly):
+    """unet_cnns.py:1977-2067: SAUnet with a one-channel polyphony regression head on the first attention layer's output."""
+
+    def __init__(self, n_chan_input=6, n_chan_layers=[64, 30, 20, 10], n_bins_in=216, n_bins_out=12,
+                 a_lrelu=0.3, p_dropout=0.2, scalefac=16, embed_dim=4 * 8, num_heads=8, mlp_dim=512, pos_encoding=None):
+        super().__init__()
+        self._build(n_chan_input, n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, scalefac, embed_dim, num_heads,
+                    mlp_dim, pos_encoding, embed_dim // 4, 1)
+
+
+class simple_u_net_doubleselfattn_polyphony_classif(_SAUnetPoly):
+    """unet_cnns.py:2070-2160: as above with `num_polyphony_steps` classes (convP: embed_dim -> embed_dim/2 -> steps)."""
+
+    def __init__(self, n_chan_input=6, n_chan_layers=[64, 30, 20, 10], n_bins_in=216, n_bins_out=12,
+                 a_lrelu=0.3, p_dropout=0.2, scalefac=16, embed_dim=4 * 8, num_heads=8, mlp_dim=512, pos_encoding=None,
+                 num_polyphony_steps=24):
+        super().__init__()
+        self._build(n_chan_input, n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, scalefac, embed_dim, num_heads,
+                    mlp_dim, pos_encoding, embed_dim // 2, num_polyphony_steps)

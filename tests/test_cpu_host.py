@@ -57,7 +57,8 @@ def test_import_surface_matches_reference():
     for n in names:
         assert hasattr(nn_models, n), n
     with pytest.raises(NotImplementedError):
-        nn_models.simple_u_net()
+        nn_models.freq_u_net_selfattn()
+    assert len(nn_models.BUILT) + len(nn_models.NOT_BUILT) == 32 and len(nn_models.NOT_BUILT) == 13
 
 
 def test_constructor_signatures_verbatim():
@@ -253,3 +254,19 @@ def test_adamw_load_state_dict_and_add_param_group_drop_the_device_tables():
     assert opt._tables == {} and opt.table_epoch == e0 + 1
     opt.add_param_group({"params": [torch.nn.Parameter(torch.zeros(2))]})
     assert opt.table_epoch == e0 + 2
+
+
+def test_variant_classes_have_the_reference_state_dict_schema():
+    """the 8 re-composed U-Net variants: key names, order and shapes as recorded from the reference classes"""
+    import json
+    import numpy as np
+    from multipitch_architectures_amd import nn_models
+    from multipitch_architectures_amd.configs import VARIANT_CONFIGS
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for name, kw in VARIANT_CONFIGS.items():
+        g = np.load(os.path.join(gdir, f"xcls-{name}.npz"))
+        want = json.loads(str(g["schema"]))
+        got = {k: list(v.shape) for k, v in getattr(nn_models, name)(**kw).state_dict().items()}
+        assert list(got) == list(want) and got == want, name
+        sig = [[q.name, q.default] for q in list(inspect.signature(getattr(nn_models, name).__init__).parameters.values())[1:]]
+        assert sig == json.loads(str(g["signature"])), name           # constructor keywords / defaults verbatim

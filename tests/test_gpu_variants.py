@@ -1,0 +1,73 @@
+"""The 8 U-Net variants the reference exports but no experiment script uses (re-compositions of the hot-path blocks,
+nn_models/unet_cnns.py bottom): HIP classes against tests/golden/xcls-*.npz, produced by the reference classes themselves
+(oracle/make_goldens_variants.py) -- evaluation outputs <= 1e-4, one train-mode step: loss and every parameter gradient."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from multipitch_architectures_amd import nn_models
+from multipitch_architectures_amd.configs import VARIANT_CONFIGS
+from multipitch_architectures_amd.losses import BCELoss
+from multipitch_architectures_amd.nn_models.layers import Dropout
+from multipitch_architectures_amd.synth import det_fill, synth_batch
+
+pytestmark = pytest.mark.gpu
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NAMES = sorted(VARIANT_CONFIGS)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _sample_idx(n, k=16):
+    return np.unique(np.linspace(0, n - 1, min(k, n)).astype(np.int64))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_variant_matches_the_reference(dev, name):
+    g = np.load(os.path.join(GOLDEN_DIR, f"xcls-{name}.npz"))
+    model = getattr(nn_models, name)(**VARIANT_CONFIGS[name])
+    assert {k: list(v.shape) for k, v in model.state_dict().items()} == json.loads(str(g["schema"]))
+    model.load_state_dict(det_fill(model.state_dict()))
+    model.to(dev).eval()
+    B, T = int(g["B"]), int(g["T"])
+    x, y = synth_batch(B, T, seed=1234)
+    x, y = x.to(dev), y.to(dev)
+    with torch.no_grad():
+        res = model(x)
+    two = isinstance(res, tuple)
+    yy = (res[0] if two else res).cpu().numpy()
+    assert np.abs(yy - g["y"]).max() <= 1e-4
+    assert (yy.reshape(B, -1, 72).argmax(-1) == g["y"].reshape(B, -1, 72).argmax(-1)).all()
+    if two:
+        ref = g["n_pred"]
+        assert np.abs(res[1].cpu().numpy() - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max())
+    for m in model.modules():
+        if isinstance(m, Dropout):
+            m.p = 0.0
+    model.train()
+    res = model(x)
+    loss = BCELoss()(res[0] if two else res, y)
+    if two:
+        loss = loss + res[1].mean() / 25.0
+    loss.backward()
+    assert abs(float(loss) - float(g["train.loss"])) <= 2e-5 * max(1.0, float(g["train.loss"]))
+    # judged against the reference run in float64 with the reference's own fp32 error as the yardstick (train-mode BatchNorm
+    # at batch 3 amplifies rounding, tests/test_gpu_models.py): 20 x that noise + 2 % of the gradient's largest entry
+    for k, p in model.named_parameters():
+        if k.endswith(("double_conv.0.bias", "double_conv.4.bias")):
+            continue        # conv bias in front of a BatchNorm: the true gradient is exactly 0, both sides hold rounding noise
+        r32 = g[f"grad.{k}.samples"].astype(np.float64)
+        r64 = g[f"grad64.{k}.samples"]
+        mine = p.grad.detach().cpu().numpy().ravel()[_sample_idx(p.numel())].astype(np.float64)
+        scale = float(g[f"grad64.{k}.absmax"])
+        tol = 20.0 * np.abs(r32 - r64).max() + 2e-2 * scale + 1e-9
+        assert np.abs(mine - r64).max() <= tol, (k, np.abs(mine - r64).max(), tol)
