@@ -3,8 +3,9 @@
 // error ~2e-5 of the result's rms on this model's data (scratch/split_bf16_error.py), inside the 1e-4 forward bound.
 // Opt-in (ops.set_conv_precision("bf16x3")); the exact-fp32 path of conv.hip stays the default and the headline.
 //
-// Replaces the same call sites as conv.hip for the 15-row filters: double_conv (unet_cnns.py:49-59) of the 75x216 and
-// 37x108 levels, conv1 / prefilt_list (basic_cnns.py:371-387).
+// Replaces the same call sites as conv.hip for the 15-row filters (all three passes) and the 9-row filters (forward and
+// backward-data): double_conv (unet_cnns.py:49-59) of the 75x216, 37x108 and 18x54 levels, conv1 / prefilt_list
+// (basic_cnns.py:371-387).
 //
 // Layouts
 //   split activations  xs[b][c/8][hi|lo][y][x][8 channels]  bf16 -- one 16-byte granule = 8 channels of one pixel, the
@@ -271,13 +272,21 @@ struct BfxPlan {
 BfxPlan bfx_plan(int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw) {
   BfxPlan pl{};
   pl.ok = false;
-  if (kh != 15 || kw < 1 || kw > 16 || sh != 1 || sw != 1) return pl;
+  if ((kh != 15 && kh != 9) || kw < 1 || kw > 16 || sh != 1 || sw != 1) return pl;
   const int OH = H + 2 * ph - kh + 1, OW = W + 2 * pw - kw + 1;
   if (OH <= 0 || OW <= 0) return pl;
   static const int forceR = getenv("MPA_BFX_R") ? atoi(getenv("MPA_BFX_R")) : 0;      // diagnostics
-  const int r15 = (int)mpa_cdiv(OH, 15) * 15, r13 = (int)mpa_cdiv(OH, 13) * 13;
-  pl.R = (r13 < r15) ? 13 : 15;
-  if (forceR == 13 || forceR == 15) pl.R = forceR;
+  // rows per wave: the candidate with the least padded rows (ties: the taller one, fewer filter-fragment reloads)
+  const int cand15[2] = {15, 13}, cand9[3] = {19, 18, 13};
+  const int* cand = kh == 15 ? cand15 : cand9;
+  const int ncand = kh == 15 ? 2 : 3;
+  long bestpad = 1L << 60;
+  for (int i = 0; i < ncand; ++i) {
+    const long pad = mpa_cdiv(OH, cand[i]) * cand[i];
+    if (pad < bestpad) { bestpad = pad; pl.R = cand[i]; }
+  }
+  for (int i = 0; i < ncand; ++i)
+    if (forceR == cand[i]) pl.R = forceR;
   pl.tilesY = (int)mpa_cdiv(OH, pl.R);
   const int cb = (int)mpa_cdiv(OW, 16);
   pl.tilesX = (int)mpa_cdiv(cb, BFX_MAXW);
@@ -321,12 +330,15 @@ int bfx_launch(const BfxGeom& g, int B, const void* xs, const void* wp, const fl
   const dim3 grid((unsigned)(mpa_cdiv(p.nTilesAll, 8) * 8 * pl.coTiles));
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv_bfx_kernel<15, 15>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_bfx_kernel<15, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define BFX_ATTR(KH_, R_) (void)hipFuncSetAttribute((const void*)conv_bfx_kernel<KH_, R_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+    BFX_ATTR(15, 15); BFX_ATTR(15, 13); BFX_ATTR(9, 19); BFX_ATTR(9, 18); BFX_ATTR(9, 13);
+#undef BFX_ATTR
     attr = true;
   }
-  if (pl.R == 15) MPA_LAUNCH((conv_bfx_kernel<15, 15>), grid, dim3(64 * pl.NW), pl.lds_bytes, s, p);
-  else MPA_LAUNCH((conv_bfx_kernel<15, 13>), grid, dim3(64 * pl.NW), pl.lds_bytes, s, p);
+#define BFX_GO(KH_, R_) MPA_LAUNCH((conv_bfx_kernel<KH_, R_>), grid, dim3(64 * pl.NW), pl.lds_bytes, s, p)
+  if (g.kh == 15) { if (pl.R == 15) BFX_GO(15, 15); else BFX_GO(15, 13); }
+  else { if (pl.R == 19) BFX_GO(9, 19); else if (pl.R == 18) BFX_GO(9, 18); else BFX_GO(9, 13); }
+#undef BFX_GO
   return mpa_launch_status();
 }
 

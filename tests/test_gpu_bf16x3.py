@@ -39,6 +39,29 @@ GEOMS = [(2, 16, 75, 216, 128, 15, 7), (2, 32, 37, 108, 32, 15, 7), (3, 6, 75, 2
          (2, 8, 16, 16, 8, 15, 7), (1, 70, 26, 40, 70, 15, 7), (2, 16, 40, 100, 16, 13, 6), (1, 3, 15, 17, 5, 15, 0)]
 
 
+# 9-row filters (forward and backward-data on the bf16x3 path; their backward-weight stays exact fp32):
+# (B, Cin, H, W, Cout) of the models' 9x9 layers + ragged ones
+GEOMS9 = [(2, 32, 18, 54, 64), (2, 64, 37, 108, 32), (3, 32, 37, 108, 16), (1, 20, 25, 40, 12), (2, 8, 9, 16, 8)]
+
+
+@pytest.mark.parametrize("geom", GEOMS9, ids=lambda g: "x".join(map(str, g)))
+def test_nine_row_filters(dev, geom):
+    B, Cin, H, W, Cout = geom
+    x = _data((B, Cin, H, W), 21, hcqt=True)
+    w = _data((Cout, Cin, 9, 9), 22) / np.sqrt(Cin * 81)
+    b = _data((Cout,), 23)
+    xd, wd = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    y = ops.conv2d(xd, wd, b.to(dev), (1, 1), (4, 4))
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    ref = F.conv2d(xr, wr, b.double(), padding=4)
+    assert (y.detach().cpu().double() - ref.detach()).abs().max().item() <= 1e-4 * max(ref.abs().max().item(), 1.0)
+    dy = _data(tuple(ref.shape), 24)
+    y.backward(dy.to(dev))
+    ref.backward(dy.double())
+    assert (xd.grad.cpu().double() - xr.grad).abs().max().item() <= 1e-4 * max(xr.grad.abs().max().item(), 1.0)
+    assert (wd.grad.cpu().double() - wr.grad).abs().max().item() <= 1e-4 * max(wr.grad.abs().max().item(), 1.0)
+
+
 @pytest.mark.parametrize("geom", GEOMS, ids=lambda g: "x".join(map(str, g)))
 def test_conv_forward_backward_data_match_float64(dev, geom):
     B, Cin, H, W, Cout, kw, pw = geom
