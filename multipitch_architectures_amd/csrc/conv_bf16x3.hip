@@ -383,6 +383,7 @@ __device__ __forceinline__ bf16x8 bfx_tr_frag(const char* lds_addr) {
   return r;
 }
 
+template <int KH>
 __global__ __launch_bounds__(512) void conv_bfx_wgrad_kernel(const BfxWgParams p) {
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   uint4* lds_x = lds;
@@ -392,13 +393,13 @@ __global__ __launch_bounds__(512) void conv_bfx_wgrad_kernel(const BfxWgParams p
   const int slice = blockIdx.x, cib = blockIdx.y, cob = blockIdx.z;
   const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
   const bool has2 = wave + 8 < p.kw;                      // second dx slot of this wave is a real tap
-  const bool dbwave = (wave + 8 == 15) || (p.kw <= 8 && wave == 7);
+  const bool dbwave = wave == 7;                          // its second tap slot (dx = 15) never holds a tap
 
-  f32x4 acc[2][15];
+  f32x4 acc[2][KH];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 15; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < KH; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // per-lane byte offset of a transposing read inside a line pair [c8 0][c8 1]: row q of the 4-pixel block, channels 4pp..
   const int lane_x = (((pp >> 1) * WG_XP + 8 * g + q) * 16) + (pp & 1) * 8;
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(512) void conv_bfx_wgrad_kernel(const BfxWgParams p
         const int dx = wave + 8 * sd;
         const char* xb = xbase + dx * 16;
 #pragma unroll
-        for (int d = 0; d < WG_R + 14; ++d) {
+        for (int d = 0; d < WG_R + KH - 1; ++d) {
           const int slot = (8 * t + 2 + d) & 31;       // ring slot of input row y0 - ph + d (wave-uniform)
           const char* xr = xb + slot * (WG_XROW * 16);
           const bf16x8 bh = bfx_tr_frag(xr);
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(512) void conv_bfx_wgrad_kernel(const BfxWgParams p
 #pragma unroll
           for (int y = 0; y < WG_R; ++y) {
             const int dy = d - y;
-            if (dy >= 0 && dy < 15) {
+            if (dy >= 0 && dy < KH) {
               acc[sd][dy] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[y], bh, acc[sd][dy], 0, 0, 0);
               acc[sd][dy] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[y], bl, acc[sd][dy], 0, 0, 0);
               acc[sd][dy] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[y], bh, acc[sd][dy], 0, 0, 0);
@@ -504,11 +505,11 @@ __global__ __launch_bounds__(512) void conv_bfx_wgrad_kernel(const BfxWgParams p
     const int dx = wave + 8 * sd;
     if (dx < p.kw && ci < p.Cin) {
 #pragma unroll
-      for (int dy = 0; dy < 15; ++dy)
+      for (int dy = 0; dy < KH; ++dy)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int co = cob * 16 + 4 * g + r;
-          if (co < p.Cout) wsb[(long)co * p.NtotP + ((long)ci * 15 + dy) * p.kw + dx] = acc[sd][dy][r];
+          if (co < p.Cout) wsb[(long)co * p.NtotP + ((long)ci * KH + dy) * p.kw + dx] = acc[sd][dy][r];
         }
     }
   }
@@ -548,9 +549,9 @@ struct BfxWgPlan { bool ok; int tilesX, strips, S, steps, coBlocks, ciBlocks, Nt
 BfxWgPlan bfx_wg_plan(const mpa_conv_desc* d) {
   BfxWgPlan pl{};
   pl.ok = false;
-  if (!d || d->kh != 15 || d->kw < 1 || d->kw > 15 || d->sh != 1 || d->sw != 1) return pl;
+  if (!d || (d->kh != 15 && d->kh != 9) || d->kw < 1 || d->kw > 15 || d->sh != 1 || d->sw != 1) return pl;
   const int OH = d->H + 2 * d->ph - d->kh + 1, OW = d->W + 2 * d->pw - d->kw + 1;
-  if (OH <= 0 || OW <= 0 || d->ph < 0 || d->ph > 14) return pl;
+  if (OH <= 0 || OW <= 0 || d->ph < 0 || d->ph > d->kh - 1) return pl;
   pl.tilesX = (int)mpa_cdiv(OW, 32);
   pl.strips = d->B * pl.tilesX;
   pl.steps = (int)mpa_cdiv(OH, WG_R);
@@ -664,11 +665,14 @@ int mpa_conv2d_bf16x3_bwd_weight(const mpa_conv_desc* d, const void* xs, const v
   hipStream_t s = (hipStream_t)stream;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv_bfx_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_bfx_wgrad_kernel<15>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_bfx_wgrad_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   const size_t lds_bytes = (size_t)(WG_XG + 2 * WG_DG) * 16;
-  MPA_LAUNCH(conv_bfx_wgrad_kernel, dim3((unsigned)pl.S, (unsigned)pl.ciBlocks, (unsigned)pl.coBlocks), dim3(512), lds_bytes, s, p);
+  const dim3 wgrid((unsigned)pl.S, (unsigned)pl.ciBlocks, (unsigned)pl.coBlocks);
+  if (d->kh == 15) MPA_LAUNCH(conv_bfx_wgrad_kernel<15>, wgrid, dim3(512), lds_bytes, s, p);
+  else MPA_LAUNCH(conv_bfx_wgrad_kernel<9>, wgrid, dim3(512), lds_bytes, s, p);
   int rc = mpa_launch_status();
   if (rc) return rc;
   const int Ntot = pl.NtotP - 1;
