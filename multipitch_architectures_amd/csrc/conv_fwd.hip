@@ -1,0 +1,723 @@
+// Implicit-GEMM 2-D convolution for gfx950 on v_mfma_f32_16x16x4_f32 (exact fp32).
+//
+// Replaces nn.Conv2d at: double_conv (unet_cnns.py:49-59), conv1/prefilt_list
+// (basic_cnns.py:371-387), conv2/conv3/conv4 (unet_cnns.py:538-557), convP (:2311-2318).
+//
+// Forward   D[cout][pixel] = sum_k Wp[cout][k] * X[k][pixel],  k = (cin, dy, dx)
+//   MFMA A operand = filters (m = cout), B operand = input halo tile in LDS
+//   (n = pixel), so the accumulator's lane index runs along pixels -> coalesced
+//   NCHW stores.  One block = 4 waves; a wave owns NB cout-blocks x PB
+//   pixel-blocks of 16x16.  The input tile (CK channels + halo) is staged once
+//   per channel chunk, the filter slab (one dy row: kw*CK*COT floats) once per
+//   (chunk, dy).
+// Backward-data = forward with flipped / transposed filters (pack mode 1).
+// Backward-weight: dW[cout][n] = sum_pixel dY[cout][pixel] * X[pixel][n],
+//   n = (cin,dy,dx) flattened; A = dY tile, B = shifted input tile, blocks loop
+//   over (image, tile) pairs and keep dW slices in registers; partials are
+//   reduced by a second kernel (deterministic, no atomics).
+// (round 3: this file holds the forward / backward-data kernel, the filter packers and their C ABI; the planners live in
+// conv_plan.h, the staging helpers in conv_stage.h, the backward-weight kernels in conv_wgrad.hip / conv_wgrad15.hip)
+#include "mpa_common.h"
+#define MPA_COMMON_CDIV 1
+#include "conv_plan.h"
+#include "conv_stage.h"
+#include "conv_internal.h"
+
+namespace {
+
+struct ConvFwdParams {
+  const float* x;
+  const float* wp;
+  const float* bias;
+  float* y;
+  int B, Cin, H, W, Cout, OH, OW, kh, kw, sh, sw, ph, pw;
+  int TH, TW, tilesY, tilesX, CK, nChunks, IH, IW, LW, CHP, COT, COTP;
+  int IN64, SL64;      // LDS words of the input tile / one filter slab, rounded up to multiples of 64
+  int quad;            // 16-byte LDS-DMA staging of the input tile (window origin rounded down to a multiple of 4)
+  int dbg;             // diagnostics (env MPA_DEBUG_FWD): 1 = stage only once, 2 = skip the MFMA loops
+  int act;
+  float slope;
+  long outBS, outCS;   // output batch / channel strides (floats)
+  int outRS, outXmul, outCdiv;
+  int outYmul, outH;   // phase stores: cout' = cin*(outXmul*outYmul) + v*outXmul + q -> row oy*outYmul+v (< outH), column ox*outXmul+q
+  int chunksPer;       // input-channel chunks per blockIdx.z slice (== nChunks when the channels are not split)
+  int coTiles, nTilesAll;   // cout tiles; pixel tiles over the whole batch
+  float* stats;             // BatchNorm fusion: per-(pixel tile, cout) partial sums of y and y^2 -> [nTilesAll][Cout][2]
+};
+
+// ------------------------------------------------------------------------------------------------ forward kernel
+// PH (phase stores): backward-data variants whose couts are (channel, x/y phase) pairs -- a separate instantiation, as
+// EF is: the 16->128 forward sits on a register cliff and lost 10 % whenever either was compiled into the common kernel
+template <int NB, int PB, int KW = 0, bool EF = false, bool PH = false>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* lds_in = lds;
+  float* lds_w0 = lds + p.IN64;          // two filter-slab buffers: slab dy+1 streams in while dy is consumed
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so workgroup w runs
+  // on XCD w%8 as the (w/8)-th of that XCD.  The coTiles workgroups that read the same input tile are made consecutive
+  // *within one XCD*: the tile is fetched from HBM once and hit in that L2 by the others.
+  const int w = blockIdx.x;
+  const int seq = w >> 3;
+  const int cot = seq % p.coTiles;
+  int bid = (seq / p.coTiles) * 8 + (w & 7);
+  if (bid >= p.nTilesAll) return;          // padding of the last group of 8 pixel tiles (whole workgroup)
+  const int ptile = bid;
+  const int tx = bid % p.tilesX;
+  bid /= p.tilesX;
+  const int ty = bid % p.tilesY;
+  const int b = bid / p.tilesY;
+  const int oy0 = ty * p.TH, ox0 = tx * p.TW;
+  const int iy0 = oy0 * p.sh - p.ph, ix0 = ox0 * p.sw - p.pw;
+  const int npix = p.TH * p.TW;
+  const int kq = lane >> 4, l16 = lane & 15;
+
+  const int x0a = p.quad ? (ix0 & ~3) : ix0;     // 4-aligned window origin for the 16-byte staging path
+  const int xshift = ix0 - x0a;
+  int boff[PB];
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb) {
+    int pix = (wave * PB + pb) * 16 + l16;
+    int pc = pix < npix ? pix : npix - 1;
+    int py = pc / p.TW, px = pc - py * p.TW;
+    boff[pb] = kq * p.CHP + py * p.sh * p.LW + px * p.sw + xshift;
+  }
+  const int aoff = kq * p.COTP + l16;
+  f32x4 acc[NB][PB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int j = 0; j < PB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const float* xb = p.x + (long)b * p.Cin * p.H * p.W;
+  constexpr int KWP = (KW + 3) & ~3;
+  const int slab = KW ? p.CK * p.COTP * KWP : p.kw * p.CK * p.COTP;
+  // tap-vector layout: lane (kq, l16) owns the KWP-tap row of (channel kq, cout l16); with 16-tap rows the four 16-byte
+  // chunks of a row are rotated by l16>>2 (done by the packer) so that 16 lanes hit 16 disjoint bank quads
+  int arow[KWP / 4 > 0 ? KWP / 4 : 1];
+  if constexpr (KW > 0) {
+#pragma unroll
+    for (int g = 0; g < KWP / 4; ++g)
+      arow[g] = (kq * p.COTP + l16) * KWP + (KWP == 16 ? ((g + (l16 >> 2)) & 3) * 4 : g * 4);
+  }
+  const float* wtile = p.wp + (long)cot * p.nChunks * p.kh * slab;
+  const int astep = p.CK * p.COTP;
+
+  EdgeFix efix;            // only live in the EF instantiations
+  (void)efix;
+  const bool split = gridDim.z > 1;
+  const int c_begin = blockIdx.z * p.chunksPer, c_end = min(p.nChunks, c_begin + p.chunksPer);
+  for (int c = c_begin; c < c_end; ++c) {
+    __syncthreads();   // every wave is done with the previous chunk's tile and slabs
+    const bool do_stage = (p.dbg != 1 && p.dbg != 3) || c == c_begin;
+    if (do_stage) {
+      if (p.quad) {
+        glds_stage_x16<EF>(lds_in, xb, lane, wave, p.CK, p.IH, p.LW, p.CHP, p.IN64, c * p.CK, iy0, x0a, p.Cin, p.H, p.W);
+        if constexpr (EF) edge_fix_load(efix, xb, tid, p.CK, p.IH, p.LW, p.CHP, c * p.CK, iy0, x0a, p.Cin, p.H, p.W, p.W);
+      } else
+        glds_stage_x(lds_in, xb, lane, wave, p.CK, p.IH, p.IW, p.LW, p.CHP, p.IN64, c * p.CK, iy0, ix0, p.Cin, p.H, p.W);
+      glds_copy16(lds_w0, wtile + (long)(c * p.kh) * slab, tid, slab / 4);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (EF) { if (p.quad && do_stage) edge_fix_store(efix, lds_in); }
+    __syncthreads();
+    for (int dy = 0; dy < p.kh; ++dy) {
+      const float* lds_w = lds_w0 + (dy & 1) * p.SL64;
+      if (dy + 1 < p.kh && do_stage)
+        glds_copy16(lds_w0 + ((dy + 1) & 1) * p.SL64, wtile + (long)(c * p.kh + dy + 1) * slab, tid, slab / 4);
+      if constexpr (KW > 0) {
+        // kw = 15 always runs with 4-channel chunks (plan_fwd), so the channel-group loop has a single trip there
+        const int nj = KW == 15 ? 1 : p.CK / 4;
+        if (p.dbg != 2)
+        for (int j = 0; j < nj; ++j) {
+          const float* aw = lds_w + (KW == 15 ? 0 : j * 4 * p.COTP * KWP);
+          const float* bp = lds_in + (KW == 15 ? 0 : j * 4 * p.CHP) + dy * p.LW;
+#pragma unroll
+          for (int g = 0; g < KWP / 4; ++g) {
+            const int taps = KW - 4 * g >= 4 ? 4 : KW - 4 * g;
+            f32x4 a4[NB];
+            float bv[4][PB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) a4[nb] = *(const f32x4*)(aw + arow[g] + nb * 16 * KWP);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (u < taps) {
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) bv[u][pb] = bp[boff[pb] + 4 * g + u];
+              }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (u < taps) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                  for (int pb = 0; pb < PB; ++pb)
+                    acc[nb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[nb][u], bv[u][pb], acc[nb][pb], 0, 0, 0);
+              }
+          }
+        }
+      } else
+      if (p.dbg != 2)
+      for (int j = 0; j < p.CK / 4; ++j) {
+        const float* ap = lds_w + j * 4 * p.COTP + aoff;
+        const float* bp = lds_in + j * 4 * p.CHP + dy * p.LW;
+        // taps in groups of 3 (kw = 15, 9, 3 for every large filter of the model): all operand reads of a group are
+        // issued before its MFMAs, the remaining latency is covered by the other resident waves
+        int dx = 0;
+        for (; dx + 3 <= p.kw; dx += 3) {
+          float a[3][NB], bv[3][PB];
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) a[u][nb] = ap[(dx + u) * astep + nb * 16];
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) bv[u][pb] = bp[boff[pb] + dx + u];
+          }
+#pragma unroll
+          for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+              for (int pb = 0; pb < PB; ++pb)
+                acc[nb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][nb], bv[u][pb], acc[nb][pb], 0, 0, 0);
+        }
+        for (; dx < p.kw; ++dx) {
+          float a[NB], bv[PB];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) a[nb] = ap[dx * astep + nb * 16];
+#pragma unroll
+          for (int pb = 0; pb < PB; ++pb) bv[pb] = bp[boff[pb] + dx];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb)
+              acc[nb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nb], bv[pb], acc[nb][pb], 0, 0, 0);
+        }
+      }
+      if (dy + 1 < p.kh && p.dbg != 3) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next slab has landed
+        __syncthreads();                                   // ... and everyone is done reading this one
+      }
+    }
+  }
+
+  // epilogue: lane holds 4 consecutive couts (rows) of one pixel (column).
+  // Wide path (NB*PB > 16, plain NCHW target, TW % 4 == 0, OW % 4 == 0): every 16x16 accumulator tile is transposed
+  // through a wave-private LDS patch so that a lane owns 4 consecutive pixels of one cout and writes one 16-byte store
+  // -- 4x fewer store instructions (measured: the 128 dword stores per lane of <4,8> cost 6.4 % of the workgroup's life).
+  if (!PH && !split && NB * PB >= 12 && p.outCdiv >= p.Cout && (p.TW & 3) == 0 && (p.OW & 3) == 0 && p.act != MPA_ACT_SIGMOID) {
+    __syncthreads();                                  // the main loop's LDS images are dead now
+    float* patch = lds + wave * (16 * 20);            // [cout 16][pixel 16 (+4 pad)]
+    const int co_l = lane >> 2, quad = lane & 3;      // after the transpose: lane -> (cout row, 4-pixel group)
+    const float neg_scale = p.act == MPA_ACT_NONE ? 1.f : (p.act == MPA_ACT_RELU ? 0.f : p.slope);
+    float* yb = p.y + (long)b * p.outBS;
+    float ssum[NB], qsum[NB];                         // BatchNorm partials (p.stats): this lane's 4-pixel groups of cout co_l
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { ssum[nb] = 0.f; qsum[nb] = 0.f; }
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+      const int pix4 = (wave * PB + pb) * 16 + quad * 4;
+      const int pc = pix4 < npix ? pix4 : 0;
+      const int py = pc / p.TW, px = pc - py * p.TW;
+      const int oy = oy0 + py, ox = ox0 + px;
+      const bool ok4 = pix4 < npix && oy < p.OH && ox < p.OW;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) patch[(kq * 4 + r) * 20 + l16] = acc[nb][pb][r];
+        __builtin_amdgcn_wave_barrier();
+        float4 v = *reinterpret_cast<const float4*>(patch + co_l * 20 + quad * 4);
+        __builtin_amdgcn_wave_barrier();
+        const int co = cot * p.COT + nb * 16 + co_l;
+        const float bs = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
+        v.x += bs; v.y += bs; v.z += bs; v.w += bs;
+        if (p.stats && ok4) {                         // (act is NONE in front of a BatchNorm)
+          ssum[nb] += (v.x + v.y) + (v.z + v.w);
+          qsum[nb] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+        v.x = v.x >= 0.f ? v.x : v.x * neg_scale; v.y = v.y >= 0.f ? v.y : v.y * neg_scale;
+        v.z = v.z >= 0.f ? v.z : v.z * neg_scale; v.w = v.w >= 0.f ? v.w : v.w * neg_scale;
+        if (ok4 && co < p.Cout)
+          *reinterpret_cast<float4*>(yb + (long)co * p.outCS + (long)oy * p.outRS + ox) = v;
+      }
+    }
+    if (p.stats) {
+      // lane quads -> one value per (wave, cout), waves -> workgroup in a fixed order, one row of partials per pixel tile
+      float* red = lds + 4 * (16 * 20);               // [wave][COT][2], behind the four transpose patches
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        float sv = ssum[nb], qv = qsum[nb];
+        sv += __shfl_xor(sv, 1, 64); qv += __shfl_xor(qv, 1, 64);
+        sv += __shfl_xor(sv, 2, 64); qv += __shfl_xor(qv, 2, 64);
+        if (quad == 0) {
+          red[(wave * p.COT + nb * 16 + co_l) * 2] = sv;
+          red[(wave * p.COT + nb * 16 + co_l) * 2 + 1] = qv;
+        }
+      }
+      __syncthreads();
+      const int co = cot * p.COT + tid;
+      if (tid < p.COT && co < p.Cout) {
+        const float s4 = (red[tid * 2] + red[(p.COT + tid) * 2]) + (red[(2 * p.COT + tid) * 2] + red[(3 * p.COT + tid) * 2]);
+        const float q4 = (red[tid * 2 + 1] + red[(p.COT + tid) * 2 + 1]) +
+                         (red[(2 * p.COT + tid) * 2 + 1] + red[(3 * p.COT + tid) * 2 + 1]);
+        *reinterpret_cast<float2*>(p.stats + ((long)ptile * p.Cout + co) * 2) = make_float2(s4, q4);
+      }
+    }
+    return;
+  }
+  if constexpr (PH && NB % 3 == 0) {
+    // stride-(1,3) backward-data with 48- or 96-cout tiles: cout' = 3*channel + phase, NB / 3 groups of 16 channels.  The
+    // three tiles of a group and pixel block go through a wave-private LDS patch; a lane then owns (channel, 4 pixels)
+    // = 12 consecutive floats of dx and writes them as three 16-byte stores (the scalar path scatters 4-byte stores 12
+    // bytes apart).  96-cout tiles halve the number of workgroups that stage the same dY tile.
+    if (!split && p.outXmul == 3 && p.outYmul == 1 && (p.TW & 3) == 0 && (p.OW & 3) == 0 && ((p.outRS * 3) & 3) == 0) {
+      __syncthreads();
+      float* patch = lds + wave * (48 * 20);           // [cout' 48][pixel 16 (+4 pad)]
+      const int cc_l = lane >> 2, quad = lane & 3;
+#pragma unroll
+      for (int grp = 0; grp < NB / 3; ++grp) {
+        const int cc = cot * (NB / 3) * 16 + grp * 16 + cc_l;      // channel of dx
+        float* yb = p.y + (long)b * p.outBS + (long)cc * p.outCS;
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+          const int pix4 = (wave * PB + pb) * 16 + quad * 4;
+          const int pc = pix4 < npix ? pix4 : 0;
+          const int py = pc / p.TW, px = pc - py * p.TW;
+          const int oy = oy0 + py, ox = ox0 + px;
+          const bool ok4 = pix4 < npix && oy < p.OH && ox < p.OW && cc < p.outCdiv;
+#pragma unroll
+          for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) patch[(nb * 16 + kq * 4 + r) * 20 + l16] = acc[grp * 3 + nb][pb][r];
+          __builtin_amdgcn_wave_barrier();
+          float o[12];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(patch + (cc_l * 3 + q) * 20 + quad * 4);
+            o[q] = t.x; o[3 + q] = t.y; o[6 + q] = t.z; o[9 + q] = t.w;
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (ok4) {
+            float* dst = yb + (long)oy * p.outRS + (long)ox * 3;
+            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            *reinterpret_cast<float4*>(dst + 8) = make_float4(o[8], o[9], o[10], o[11]);
+          }
+        }
+      }
+      return;
+    }
+  }
+  if constexpr (!PH) {
+    if (p.stats) {
+      // BatchNorm partials from the accumulators (+ bias): lane (kq, l16) holds couts nb*16 + kq*4 + r of pixel l16 of
+      // each of its PB blocks; sum its valid pixels, then the 16 pixel lanes, then the four waves through LDS
+      __syncthreads();                                  // the main loop's LDS images are dead now
+      float* red = lds;                                 // [wave][COT][2]
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = nb * 16 + kq * 4 + r, co = cot * p.COT + col;
+          const float bs = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
+          float sv = 0.f, qv = 0.f;
+#pragma unroll
+          for (int pb = 0; pb < PB; ++pb) {
+            const int pix = (wave * PB + pb) * 16 + l16;
+            const int pc = pix < npix ? pix : 0;
+            const int py = pc / p.TW, px = pc - py * p.TW;
+            const bool ok = pix < npix && oy0 + py < p.OH && ox0 + px < p.OW;
+            const float v = acc[nb][pb][r] + bs;
+            if (ok) { sv += v; qv += v * v; }
+          }
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) { sv += __shfl_xor(sv, o, 64); qv += __shfl_xor(qv, o, 64); }
+          if (l16 == 0) { red[(wave * p.COT + col) * 2] = sv; red[(wave * p.COT + col) * 2 + 1] = qv; }
+        }
+      }
+      __syncthreads();
+      const int co = cot * p.COT + tid;
+      if (tid < p.COT && co < p.Cout) {
+        const float s4 = (red[tid * 2] + red[(p.COT + tid) * 2]) + (red[(2 * p.COT + tid) * 2] + red[(3 * p.COT + tid) * 2]);
+        const float q4 = (red[tid * 2 + 1] + red[(p.COT + tid) * 2 + 1]) +
+                         (red[(2 * p.COT + tid) * 2 + 1] + red[(3 * p.COT + tid) * 2 + 1]);
+        *reinterpret_cast<float2*>(p.stats + ((long)ptile * p.Cout + co) * 2) = make_float2(s4, q4);
+      }
+    }
+  }
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb) {
+    const int pix = (wave * PB + pb) * 16 + l16;
+    if (pix >= npix) continue;
+    const int py = pix / p.TW, px = pix - py * p.TW;
+    const int oy = oy0 + py, ox = ox0 + px;
+    if (oy >= p.OH || ox >= p.OW) continue;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = cot * p.COT + nb * 16 + kq * 4 + r;
+        if (co >= p.Cout) continue;
+        float v = acc[nb][pb][r];
+        if (p.bias && blockIdx.z == 0) v += p.bias[co];
+        float* dst;
+        if constexpr (!PH) {                  // plain NCHW store
+          dst = p.y + (long)b * p.outBS + (long)co * p.outCS + (long)oy * p.outRS + ox;
+        } else {
+          // cout' = cin*(PX*PY) + v*PX + q: x phase q (stride-(1,kw) backward-data: the kw phases of a pixel are adjacent
+          // floats of dx, written by one workgroup) and/or y phase v (few-channel layers: V output rows per cout block)
+          const int nph = p.outXmul * p.outYmul;
+          const int cc = co / nph, phi = co - cc * nph;
+          const int vph = phi / p.outXmul, q = phi - vph * p.outXmul;
+          const int row = oy * p.outYmul + vph;
+          if (row >= p.outH) continue;
+          dst = p.y + (long)b * p.outBS + (long)cc * p.outCS + (long)row * p.outRS + (long)ox * p.outXmul + q;
+        }
+        if (split) atomicAdd(dst, v);         // channel slices accumulate into the zeroed output; activation follows
+        else *dst = mpa_apply_act(v, p.act, p.slope);
+      }
+    }
+  }
+}
+
+template <int NB, int PB, int KW, bool EF, bool PH = false>
+int launch_fwd_ef(const FwdPlan& pl, const ConvFwdParams& p, dim3 grid, hipStream_t s) {
+  static bool big_lds = false;
+  if (!big_lds) {
+    (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<NB, PB, KW, EF, PH>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              80 * 1024);
+    big_lds = true;
+  }
+  MPA_LAUNCH((conv_fwd_kernel<NB, PB, KW, EF, PH>), grid, dim3(256), pl.lds_bytes, s, p);
+  return mpa_launch_status();
+}
+
+template <int NB, int PB, int KW>
+int launch_fwd_one(const FwdPlan& pl, const ConvFwdParams& p, dim3 grid, hipStream_t s) {
+  // no edge-fix build for the 15x15 / 9x9 specialisations: they serve widths 216 and 108, and their register budget is
+  // tight
+  if (p.outCdiv < p.Cout) {               // phase stores: built for the generic and the 15-tap loops only (plan_fwd)
+    if constexpr (KW == 0 || KW == 15) return launch_fwd_ef<NB, PB, KW, false, true>(pl, p, grid, s);
+    return MPA_ERR_UNSUPPORTED;
+  }
+  if constexpr (KW < 9) {
+    if (p.quad && (p.W & 3)) return launch_fwd_ef<NB, PB, KW, true>(pl, p, grid, s);
+  }
+  return launch_fwd_ef<NB, PB, KW, false>(pl, p, grid, s);
+}
+
+template <int NB, int PB>
+int launch_fwd_kw(const FwdPlan& pl, const ConvFwdParams& p, dim3 grid, hipStream_t s) {
+  if constexpr (PB >= 4 && (NB <= 2 || NB * PB <= 30)) {
+    if (pl.KWS == 15) return launch_fwd_one<NB, PB, 15>(pl, p, grid, s);
+    if (pl.KWS == 9) return launch_fwd_one<NB, PB, 9>(pl, p, grid, s);
+    if (pl.KWS == 5) return launch_fwd_one<NB, PB, 5>(pl, p, grid, s);
+    if (pl.KWS == 3) return launch_fwd_one<NB, PB, 3>(pl, p, grid, s);
+  }
+  if (pl.KWS != 0) return MPA_ERR_UNSUPPORTED;
+  return launch_fwd_one<NB, PB, 0>(pl, p, grid, s);
+}
+
+template <int NB>
+int launch_fwd_nb(const FwdPlan& pl, const ConvFwdParams& p, hipStream_t s) {
+  dim3 grid((unsigned)(mpa_cdiv(p.nTilesAll, 8) * 8 * pl.coTiles), 1, (unsigned)mpa_cdiv(pl.nChunks, p.chunksPer));
+  switch (pl.PB) {
+    case 1: return launch_fwd_kw<NB, 1>(pl, p, grid, s);
+    case 2: return launch_fwd_kw<NB, 2>(pl, p, grid, s);
+    case 4: return launch_fwd_kw<NB, 4>(pl, p, grid, s);
+    case 6: return launch_fwd_kw<NB, 6>(pl, p, grid, s);
+    case 8:
+      if constexpr (NB <= 4) return launch_fwd_kw<NB, 8>(pl, p, grid, s);
+      return MPA_ERR_UNSUPPORTED;
+    case 12:
+      if constexpr (NB <= 2) return launch_fwd_kw<NB, 12>(pl, p, grid, s);
+      return MPA_ERR_UNSUPPORTED;
+    default: return MPA_ERR_UNSUPPORTED;
+  }
+}
+
+int launch_fwd_nb3(const FwdPlan& pl, const ConvFwdParams& p, hipStream_t s) {      // phase-store builds only
+  dim3 grid((unsigned)(mpa_cdiv(p.nTilesAll, 8) * 8 * pl.coTiles), 1, (unsigned)mpa_cdiv(pl.nChunks, p.chunksPer));
+  if (pl.KWS != 0 || p.outCdiv >= p.Cout) return MPA_ERR_UNSUPPORTED;
+  switch (pl.PB) {
+    case 4: return launch_fwd_ef<3, 4, 0, false, true>(pl, p, grid, s);
+    case 6: return launch_fwd_ef<3, 6, 0, false, true>(pl, p, grid, s);
+    case 8: return launch_fwd_ef<3, 8, 0, false, true>(pl, p, grid, s);
+    default: return MPA_ERR_UNSUPPORTED;
+  }
+}
+
+int launch_fwd_nb6(const FwdPlan& pl, const ConvFwdParams& p, hipStream_t s) {      // 96-cout phase tiles
+  dim3 grid((unsigned)(mpa_cdiv(p.nTilesAll, 8) * 8 * pl.coTiles), 1, (unsigned)mpa_cdiv(pl.nChunks, p.chunksPer));
+  if (pl.KWS != 0 || p.outCdiv >= p.Cout || pl.PB != 4) return MPA_ERR_UNSUPPORTED;
+  return launch_fwd_ef<6, 4, 0, false, true>(pl, p, grid, s);
+}
+
+int launch_fwd(const FwdPlan& pl, const ConvFwdParams& p, hipStream_t s) {
+  switch (pl.NB) {
+    case 3: return launch_fwd_nb3(pl, p, s);
+    case 6: return launch_fwd_nb6(pl, p, s);
+    case 1: return launch_fwd_nb<1>(pl, p, s);
+    case 2: return launch_fwd_nb<2>(pl, p, s);
+    case 4: return launch_fwd_nb<4>(pl, p, s);
+    case 5: return launch_fwd_nb<5>(pl, p, s);
+    default: return MPA_ERR_UNSUPPORTED;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ filter packing
+// packed[cot][chunk][dy][dx][ck][COTP]
+//   mode 0 (forward)      : value = w[co][ci][dy][dx]
+//   mode 1 (backward-data): the derived conv has Cin' = Cout, Cout' = Cin (stride 1) or kw*Cin (stride == kernel
+//                           along W), value = w[ci'][co' % Cin][kh-1-dy][dxsel]
+struct PackParams {
+  const float* w;
+  float* wp;
+  int Cout_w, Cin_w, kh_w, kw_w;   // original filter dims
+  int mode, xphase;                // xphase: strided-W backward (dx taken from co' / Cin)
+  int yphase;                      // V > 1: cout'' = cin*V + v with the flipped filter shifted down by v rows
+  int CinP, CoutP, kh, kw;         // dims of the conv that will consume the packed filters
+  int CK, nChunks, COT, COTP, coTiles;
+  int KWP;                         // > 0: tap-vector layout packed[cot][chunk][dy][ck][COT][KWP] (see fwd_kw_special)
+  long total;
+};
+
+__device__ __forceinline__ void conv_pack_range(const PackParams& p, long first, long step) {
+  for (long i = first; i < p.total; i += step) {
+    long r = i;
+    int col, ck, dx;
+    if (p.KWP > 0) {
+      int pos = (int)(r % p.KWP); r /= p.KWP;
+      col = (int)(r % p.COTP); r /= p.COTP;
+      ck = (int)(r % p.CK); r /= p.CK;
+      // 16-tap rows: chunk g of the row sits at position (g + (col&15)>>2) & 3 -- undo the rotation to find the tap
+      if (p.KWP == 16) pos = ((((pos >> 2) - ((col & 15) >> 2)) & 3) << 2) | (pos & 3);
+      dx = pos;
+    } else {
+      col = (int)(r % p.COTP); r /= p.COTP;
+      ck = (int)(r % p.CK); r /= p.CK;
+      dx = (int)(r % p.kw); r /= p.kw;
+    }
+    const int dy = (int)(r % p.kh); r /= p.kh;
+    const int chunk = (int)(r % p.nChunks); r /= p.nChunks;
+    const int cot = (int)r;
+    const int co = cot * p.COT + col, ci = chunk * p.CK + ck;
+    float v = 0.f;
+    if (col < p.COT && co < p.CoutP && ci < p.CinP && dx < p.kw) {
+      if (p.mode == 0) {
+        v = p.w[(((long)co * p.Cin_w + ci) * p.kh_w + dy) * p.kw_w + dx];
+      } else if (p.yphase > 1) {
+        const int cc = co / p.yphase, dyo = dy - (co - cc * p.yphase);
+        if (dyo >= 0 && dyo < p.kh_w)
+          v = p.w[(((long)ci * p.Cin_w + cc) * p.kh_w + (p.kh_w - 1 - dyo)) * p.kw_w + (p.kw_w - 1 - dx)];
+      } else if (!p.xphase) {
+        v = p.w[(((long)ci * p.Cin_w + co) * p.kh_w + (p.kh_w - 1 - dy)) * p.kw_w + (p.kw_w - 1 - dx)];
+      } else {
+        const int cc = co / p.kw_w, q = co - cc * p.kw_w;    // cout' = cin*kw + dx phase (see the epilogue)
+        v = p.w[(((long)ci * p.Cin_w + cc) * p.kh_w + (p.kh_w - 1 - dy)) * p.kw_w + q];
+      }
+    }
+    p.wp[i] = v;
+  }
+}
+
+__global__ void conv_pack_kernel(const PackParams p) {
+  conv_pack_range(p, blockIdx.x * (long)blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+
+// every filter bank of a model in one launch: blockIdx.y = entry of a device-resident table of PackParams (the training
+// step re-packs ~44 banks after each optimizer step; as 44 launches that was 0.21 ms of a 28 ms step at local batch 32)
+__global__ void conv_pack_many_kernel(const PackParams* __restrict__ table) {
+  const PackParams p = table[blockIdx.y];
+  conv_pack_range(p, blockIdx.x * (long)blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+int64_t mpa_conv2d_packed_floats(const mpa_conv_desc* d, int mode) {
+  if (!d) return MPA_ERR_ARG;
+  FwdPlan pl;
+  int kh = d->kh, kw = d->kw;
+  if (mode == 0) {
+    pl = plan_fwd(d->B, d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw);
+  } else {
+    BwdDataGeom g = bwd_data_geom(d);
+    if (!g.ok) return MPA_ERR_UNSUPPORTED;
+    pl = plan_bwd_data(d, g);
+    kh = g.kh; kw = g.kw;
+  }
+  if (!pl.ok) return MPA_ERR_UNSUPPORTED;
+  return (int64_t)pl.coTiles * pl.nChunks * kh * (pl.KWS ? pl.KWP : kw) * pl.CK * pl.COTP;
+}
+
+static int pack_params(const mpa_conv_desc* d, int mode, const float* w, float* w_packed, PackParams& p);
+
+int mpa_conv2d_pack(const mpa_conv_desc* d, int mode, const float* w, float* w_packed, void* stream) {
+  if (!d || !w || !w_packed) return MPA_ERR_ARG;
+  PackParams p{};
+  const int rc = pack_params(d, mode, w, w_packed, p);
+  if (rc) return rc;
+  const int blocks = (int)std::min<long>(mpa_cdiv(p.total, 256), 4096);
+  MPA_LAUNCH(conv_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  return mpa_launch_status();
+}
+
+int mpa_conv2d_pack_entry_bytes(void) { return (int)sizeof(PackParams); }
+
+int mpa_conv2d_pack_entry(const mpa_conv_desc* d, int mode, const float* w, float* w_packed, void* host_entry) {
+  if (!d || !w || !w_packed || !host_entry) return MPA_ERR_ARG;
+  PackParams p{};
+  const int rc = pack_params(d, mode, w, w_packed, p);
+  if (rc) return rc;
+  memcpy(host_entry, &p, sizeof(PackParams));
+  return MPA_OK;
+}
+
+int mpa_conv2d_pack_many(const void* device_table, int n, void* stream) {
+  if (!device_table || n < 0) return MPA_ERR_ARG;
+  if (n == 0) return MPA_OK;
+  if (n > 65535) return MPA_ERR_ARG;
+  MPA_LAUNCH(conv_pack_many_kernel, dim3(64, (unsigned)n), dim3(256), 0, (hipStream_t)stream, (const PackParams*)device_table);
+  return mpa_launch_status();
+}
+
+static int pack_params(const mpa_conv_desc* d, int mode, const float* w, float* w_packed, PackParams& p) {
+  p.w = w; p.wp = w_packed;
+  p.Cout_w = d->Cout; p.Cin_w = d->Cin; p.kh_w = d->kh; p.kw_w = d->kw;
+  p.mode = mode; p.xphase = 0;
+  FwdPlan pl;
+  if (mode == 0) {
+    pl = plan_fwd(d->B, d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw);
+    p.CinP = d->Cin; p.CoutP = d->Cout; p.kh = d->kh; p.kw = d->kw;
+  } else {
+    BwdDataGeom g = bwd_data_geom(d);
+    if (!g.ok) return MPA_ERR_UNSUPPORTED;
+    pl = plan_bwd_data(d, g);
+    p.CinP = g.Cin; p.CoutP = g.Cout; p.kh = g.kh; p.kw = g.kw; p.xphase = g.xphase ? 1 : 0; p.yphase = g.yphase;
+  }
+  if (!pl.ok) return MPA_ERR_UNSUPPORTED;
+  p.CK = pl.CK; p.nChunks = pl.nChunks; p.COT = pl.COT; p.COTP = pl.COTP; p.coTiles = pl.coTiles;
+  p.KWP = pl.KWS ? pl.KWP : 0;
+  p.total = (long)pl.coTiles * pl.nChunks * p.kh * (pl.KWS ? pl.KWP : p.kw) * pl.CK * pl.COTP;
+  return MPA_OK;
+}
+
+static int conv_fwd_impl(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                         const float* x, const float* wp, const float* bias, float* y, int act, float slope,
+                         long outBS, long outCS, int outRS, int outXmul, int outCdiv, hipStream_t s, bool allow_split = false,
+                         int Hplan = 0, int outYmul = 1, int outH = 0, float* stats = nullptr) {
+  FwdPlan pl = plan_fwd(B, Cin, Hplan ? Hplan : H, W, Cout, kh, kw, sh, sw, ph, pw, allow_split, outCdiv < Cout,
+                        outCdiv < Cout ? outXmul : 1);
+  if (!pl.ok) return MPA_ERR_UNSUPPORTED;
+  if (stats) {
+    if (pl.KS > 1 || act != MPA_ACT_NONE) return MPA_ERR_UNSUPPORTED;
+    pl.lds_bytes = std::max<size_t>(pl.lds_bytes, 8192);      // the epilogue's reduction scratch (tiny tiles stage less)
+  }
+  ConvFwdParams p{};
+  p.x = x; p.wp = wp; p.bias = bias; p.y = y;
+  p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.OH = pl.OH; p.OW = pl.OW;
+  p.kh = kh; p.kw = kw; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw;
+  p.TH = pl.TH; p.TW = pl.TW; p.tilesY = pl.tilesY; p.tilesX = pl.tilesX; p.CK = pl.CK; p.nChunks = pl.nChunks;
+  p.IH = pl.IH; p.IW = pl.IW; p.LW = pl.LW; p.CHP = pl.CHP; p.COT = pl.COT; p.COTP = pl.COTP;
+  p.IN64 = (int)(mpa_cdiv((long)pl.CK * pl.CHP, 64) * 64);
+  p.SL64 = (int)(mpa_cdiv((long)(pl.KWS ? pl.KWP : kw) * pl.CK * pl.COTP, 64) * 64);
+  p.quad = pl.quad;
+  { const char* e = getenv("MPA_DEBUG_FWD"); p.dbg = e ? atoi(e) : 0; }
+  p.act = act; p.slope = slope;
+  p.outBS = outBS; p.outCS = outCS; p.outRS = outRS; p.outXmul = outXmul; p.outCdiv = outCdiv;
+  p.outYmul = outYmul; p.outH = outH ? outH : pl.OH;
+  p.chunksPer = (int)mpa_cdiv(pl.nChunks, pl.KS);
+  p.coTiles = pl.coTiles; p.nTilesAll = B * pl.tilesY * pl.tilesX;
+  p.stats = stats;
+  if (mpa_cdiv(pl.nChunks, p.chunksPer) <= 1) return launch_fwd(pl, p, s);
+  // channel-split launch: slices add into a zeroed output, the activation (if any) runs afterwards in place
+  if (mpa_zero_async(y, sizeof(float) * (size_t)B * (size_t)outBS, s) != MPA_OK) return MPA_ERR_LAUNCH;
+  p.act = MPA_ACT_NONE;
+  const int rc = launch_fwd(pl, p, s);
+  if (rc != MPA_OK || act == MPA_ACT_NONE) return rc;
+  return mpa_act_fwd(y, y, (int64_t)B * outBS, act, slope, s);
+}
+
+int mpa_conv2d_fwd(const mpa_conv_desc* d, const float* x, const float* w_packed, const float* bias, float* y,
+                   int act, float slope, void* stream) {
+  if (!d || !x || !w_packed || !y || d->B <= 0) return MPA_ERR_ARG;
+  const int OH = (d->H + 2 * d->ph - d->kh) / d->sh + 1, OW = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
+  if (OH <= 0 || OW <= 0) return MPA_ERR_ARG;
+  return conv_fwd_impl(d->B, d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw, x, w_packed, bias,
+                       y, act, slope, (long)d->Cout * OH * OW, (long)OH * OW, OW, 1, d->Cout, (hipStream_t)stream);
+}
+
+int64_t mpa_conv2d_fwd_stats_rows(const mpa_conv_desc* d) {
+  if (!d) return MPA_ERR_ARG;
+  FwdPlan pl = plan_fwd(d->B, d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw);
+  if (!pl.ok) return MPA_ERR_UNSUPPORTED;
+  return (int64_t)d->B * pl.tilesY * pl.tilesX;
+}
+
+int mpa_conv2d_fwd_stats(const mpa_conv_desc* d, const float* x, const float* w_packed, const float* bias, float* y,
+                         float* partials, void* stream) {
+  if (!d || !x || !w_packed || !y || !partials || d->B <= 0) return MPA_ERR_ARG;
+  const int OH = (d->H + 2 * d->ph - d->kh) / d->sh + 1, OW = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
+  if (OH <= 0 || OW <= 0) return MPA_ERR_ARG;
+  return conv_fwd_impl(d->B, d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw, x, w_packed, bias,
+                       y, MPA_ACT_NONE, 0.f, (long)d->Cout * OH * OW, (long)OH * OW, OW, 1, d->Cout, (hipStream_t)stream,
+                       false, 0, 1, 0, partials);
+}
+
+int mpa_conv2d_bwd_data(const mpa_conv_desc* d, const float* dy, const float* w_packed, float* dx, void* stream) {
+  if (!d || !dy || !w_packed || !dx || d->B <= 0) return MPA_ERR_ARG;
+  BwdDataGeom g = bwd_data_geom(d);
+  if (!g.ok) return MPA_ERR_UNSUPPORTED;
+  const long inBS = (long)d->Cin * d->H * d->W, inCS = (long)d->H * d->W;
+  if (g.yphase > 1) {
+    // V output rows per cout block: derived conv with vertical stride V; row oy*V + v of channel cout''/V
+    return conv_fwd_impl(d->B, g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, g.sh, 1, g.ph, g.pw, dy, w_packed, nullptr, dx,
+                         MPA_ACT_NONE, 0.f, inBS, inCS, d->W, 1, d->Cin, (hipStream_t)stream, true, g.Hplan, g.yphase,
+                         d->H);
+  }
+  if (!g.xphase) {
+    // output of the derived conv has size H x W again
+    return conv_fwd_impl(d->B, g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw, dy, w_packed, nullptr, dx,
+                         MPA_ACT_NONE, 0.f, inBS, inCS, d->W, 1, g.Cout, (hipStream_t)stream, true);
+  }
+  return conv_fwd_impl(d->B, g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, 1, 1, g.ph, g.pw, dy, w_packed, nullptr, dx,
+                       MPA_ACT_NONE, 0.f, inBS, inCS, d->W, d->sw, d->Cin, (hipStream_t)stream, true);
+}
+
+int mpa_conv2d_describe_plan(const mpa_conv_desc* d, int mode, char* buf, int buflen) {
+  if (!d || !buf || buflen <= 0) return MPA_ERR_ARG;
+  if (mode == 2) {
+    Wg15Plan q = plan_wgrad15(d);
+    if (q.ok) {
+      int n = snprintf(buf, buflen, "wgrad15%s<%d,%d> COT=%d coTiles=%d ciGroups=%d tile=%dx%d (DP %d) tiles=%dx%d S=%d lds=%zuB",
+                       q.ga ? "g" : "", q.NBC, q.CIW, q.COT, q.coTiles, q.ciGroups, q.TH, q.TW, q.DP, q.tilesY, q.tilesX, q.S, q.lds_bytes);
+      if (q.ga && n > 0 && n < buflen)
+        snprintf(buf + n, buflen - n, " launches: %dx32 %s fold=%d (NT %d, tile rows %d x %d)", q.n32, q.has16 ? "+16" : "",
+                 q.fold_R, q.fold_NT, q.fTH, q.ftilesY);
+      return MPA_OK;
+    }
+    WgPlan w = plan_wgrad(d);
+    if (!w.ok) return MPA_ERR_UNSUPPORTED;
+    snprintf(buf, buflen, "wgrad%s<%d,%d> COT=%d coTiles=%d nPerBlock=%d nTiles=%d XCH=%d tile=%dx%d (DP %d) tiles=%dx%d S=%d quad=%d ef=%d lds=%zuB",
+             w.ga ? "_g" : "", w.NBC, w.NTW, w.COT, w.coTiles, w.nPerBlock, w.nTiles, w.XCH, w.TH, w.TW, w.DP, w.tilesY,
+             w.tilesX, w.S, w.quad, w.ef, w.lds_bytes);
+    return MPA_OK;
+  }
+  FwdPlan f;
+  if (mode == 0) f = plan_fwd(d->B, d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw);
+  else {
+    BwdDataGeom g = bwd_data_geom(d);
+    if (!g.ok) return MPA_ERR_UNSUPPORTED;
+    f = plan_bwd_data(d, g);
+  }
+  if (!f.ok) return MPA_ERR_UNSUPPORTED;
+  snprintf(buf, buflen, "fwd<%d,%d> COT=%d coTiles=%d CK=%d chunks=%d tile=%dx%d tiles=%dx%d halo=%dx%d LW=%d quad=%d kwvec=%d ksplit=%d lds=%zuB",
+           f.NB, f.PB, f.COT, f.coTiles, f.CK, f.nChunks, f.TH, f.TW, f.tilesY, f.tilesX, f.IH, f.IW, f.LW, f.quad, f.KWS, f.KS, f.lds_bytes);
+  return MPA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,55 @@
+"""The convolution planners are host-only C++ (csrc/conv_plan.h, split out of the kernel files in round 3): this test
+compiles them with g++ alone -- no hipcc, no GPU -- and checks the plans of the models' layers: every plan exists, fits the
+LDS budget, its tiles cover the output, and the choices DESIGN.md quotes are the ones made."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def plans(tmp_path_factory):
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("g++ not available")
+    exe = str(tmp_path_factory.mktemp("plan") / "plan_driver")
+    subprocess.run([gxx, "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "cpp", "plan_driver.cpp")], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    res = {}
+    for ln in out.splitlines():
+        name, kind, rest = ln.split(" ", 2)
+        res[(name, kind)] = {k: int(v) for k, v in re.findall(r"(\w+)=(-?\d+)", rest)}
+    return res
+
+
+def test_every_layer_has_a_plan_that_fits(plans):
+    for (name, kind), p in plans.items():
+        if name == "strided_unsupported":
+            continue
+        assert p["ok"] == 1, (name, kind)
+        assert p["lds"] <= 160 * 1024, (name, kind, p)
+        if kind in ("fwd", "dgrad"):
+            assert p["tilesY"] * p["TH"] >= p["OH"] and p["tilesX"] * p["TW"] >= p["OW"], (name, kind, p)
+            assert p["TH"] * p["TW"] <= p["PB"] * 64, (name, kind, p)             # a tile fits the block's pixel lanes
+            assert p["coTiles"] * p["COT"] >= 1
+
+
+def test_unsupported_geometry_is_reported_not_planned(plans):
+    assert plans[("strided_unsupported", "dgrad")]["ok"] == 0      # stride (2,2) has no backward-data decomposition
+
+
+def test_the_choices_design_md_quotes(plans):
+    f = plans[("upconv4b", "fwd")]
+    assert (f["NB"], f["PB"], f["KWS"], f["KS"]) == (2, 12, 15, 1)      # conv_fwd_kernel<2,12,15>: the roofline kernel
+    d = plans[("upconv4b", "dgrad")]
+    assert (d["NB"], d["PB"], d["KWS"]) == (1, 12, 15)
+    assert plans[("upconv4b_b32", "dgrad")]["KS"] > 1                   # small grid: channel slices level the tile count
+    w = plans[("upconv4b", "wgrad15")]
+    assert w["ga"] == 1 and w["n32"] == 4 and w["fold"] == 0
+    p = plans[("prefilt", "wgrad15")]
+    assert (p["n32"], p["has16"], p["fold"]) == (2, 0, 6)               # 70 couts = 2 x 32 + tap-folded 6
+    assert plans[("conv2_80", "wgrad")]["NBC"] == 5                     # head conv2: 80-cout block shape
