@@ -319,6 +319,35 @@ int mpa_annotation_array_nooverlap(const double* note_events, int ev_stride, int
                                    int kind, int n_frames, double* out, void* workspace, int64_t workspace_bytes,
                                    void* stream);
 
+/* ------------------------------------------------------------------ HCQT front-end (second half) -- PARITY UNPINNED
+ * The arithmetic of compute_efficient_hcqt (libdl/data_preprocessing/hcqt.py:89-164).  The reference delegates to librosa 0.8
+ * (librosa.cqt, librosa.estimate_tuning -- third-party, absent from the image): these entry points implement the published
+ * algorithm as restated in oracle/restate_hcqt.py (librosa's constant-Q filter bank evaluated directly at the original rate
+ * instead of by its octave-wise resampling recursion) and are checked against that restatement only.  The products
+ * "signal frames x basis" run through mpa_gemm with a strided A operand (A(m,k) = y[m*hop + k]).                          */
+/* out[i] = y[reflect(i - pad_l)], i < n + pad_l + pad_r (numpy mode="reflect") */
+int mpa_reflect_pad(const float* y, int64_t n, int64_t pad_l, int64_t pad_r, float* out, void* stream);
+/* B [n_fft][2*(n_fft/2+1)]: periodic-Hann-windowed DFT basis, columns (re, -im) per frequency bin */
+int mpa_stft_basis(float* B, int n_fft, void* stream);
+/* S[i] = |(C[2i], C[2i+1])| */
+int mpa_complex_mag(const float* C, float* S, int64_t n, void* stream);
+/* librosa piptrack on S [frames][n_fft/2+1]: candidates (pitch in Hz, interpolated magnitude) appended to pitch / mag
+ * (capacity frames * ((nb+1)/2)), their number in *count (device int)                                                    */
+int mpa_piptrack(const float* S, int64_t frames, int nb, double sr, int n_fft, double fmin, double fmax, double threshold,
+                 double* pitch, float* mag, int* count, void* stream);
+/* librosa estimate_tuning's tail: candidates at or above the median magnitude -> pitch_tuning histogram -> *tuning_out
+ * (device double, fraction of a bin in [-0.5, 0.5)); n = the count read back from mpa_piptrack                           */
+int64_t mpa_pitch_tuning_workspace(int64_t n);
+int mpa_pitch_tuning(const double* pitch, const float* mag, int64_t n, int bins_per_octave, double resolution,
+                     double* tuning_out, void* ws, int64_t ws_bytes, void* stream);
+/* constant-Q basis of nb consecutive bins starting at frequency f0: B [K][ncols], columns (re, -im) per bin, row k = sample
+ * offset k - K0 from the frame centre; filters of librosa.filters.constant_q (Hann, L1-normalised) times sqrt(length)      */
+int mpa_cqt_basis(float* B, int64_t K, int64_t K0, int ncols, double f0, int nb, int bins_per_octave, double sr, void* stream);
+/* magnitudes of one bin group C [frames][ncols] into the HCQT tensor out [n_bins_out][frames][n_harm]: bin bin0+j becomes
+ * row bin0+j-fac_bins[m] of harmonic hidx[m] for each of the nmem <= 8 members whose slice contains it (host arrays)     */
+int mpa_cqt_mag_scatter(const float* C, int64_t frames, int ncols, int nb, int bin0, float* out, int n_bins_out, int n_harm,
+                        const int* fac_bins, const int* hidx, int nmem, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

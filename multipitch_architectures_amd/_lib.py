@@ -117,6 +117,14 @@ SIGNATURES = {
     "mpa_eval_measures": (c_int, [_P, _P, c_int64, c_int, c_double, _P, _P, c_int64, _P]),
     "mpa_annotation_workspace": (c_int64, [c_int]),
     "mpa_annotation_array_nooverlap": (c_int, [_P, c_int, c_int, c_double, c_double, c_int, c_int, _P, _P, c_int64, _P]),
+    "mpa_reflect_pad": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
+    "mpa_stft_basis": (c_int, [_P, c_int, _P]),
+    "mpa_complex_mag": (c_int, [_P, _P, c_int64, _P]),
+    "mpa_piptrack": (c_int, [_P, c_int64, c_int, c_double, c_int, c_double, c_double, c_double, _P, _P, _P, _P]),
+    "mpa_pitch_tuning_workspace": (c_int64, [c_int64]),
+    "mpa_pitch_tuning": (c_int, [_P, _P, c_int64, c_int, c_double, _P, _P, c_int64, _P]),
+    "mpa_cqt_basis": (c_int, [_P, c_int64, c_int64, c_int, c_double, c_int, c_int, c_double, _P]),
+    "mpa_cqt_mag_scatter": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, c_int, _P]),
     "mpa_adamw_step": (c_int, [_P, _P, _P, _P, _P, c_int, c_int64, _P, c_double, c_double, c_double, c_double, _P]),
 }
 

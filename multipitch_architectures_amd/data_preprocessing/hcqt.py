@@ -1,13 +1,19 @@
 """Pre-processing either side of the HCQT -- drop-in for the functions of
 libdl/data_preprocessing/hcqt.py that 01_precompute_features.ipynb / 02_predict_with_pretrained_model.ipynb call.
 
-Built: ``compute_hopsize_cqt`` (:9-27, scalar arithmetic) and ``compute_annotation_array_nooverlap`` (:205-272, the note
-list -> piano roll conversion: a HIP kernel through the C ABI, bit-exact with the reference -- tests/test_gpu_annot.py
+Built and pinned: ``compute_hopsize_cqt`` (:9-27, scalar arithmetic) and ``compute_annotation_array_nooverlap`` (:205-272, the
+note list -> piano roll conversion: a HIP kernel through the C ABI, bit-exact with the reference -- tests/test_gpu_annot.py
 against fixtures produced by the reference's own function on the note list it ships).
-Not built: ``compute_hcqt`` / ``compute_efficient_hcqt`` (:31-164) -- they are thin loops around ``librosa.cqt`` and
-``librosa.estimate_tuning`` (third-party, absent from the image: no executable truth to pin a re-implementation to);
-they raise ``NotImplementedError``.  ``compute_annotation_array`` (:167-202) has no ``return`` in the reference (it yields
-``None``) and no caller; it is not provided.
+Built, **parity unpinned**: ``compute_hcqt`` / ``compute_efficient_hcqt`` (:31-164).  In the reference they are thin loops
+around ``librosa.cqt`` and ``librosa.estimate_tuning`` (librosa 0.8, third-party, absent from the image: no executable truth
+and no fixture to pin a re-implementation to).  Here the published algorithm runs on the GPU -- piptrack / tuning histogram
+as kernels, the constant-Q filter bank (librosa's ``filters.constant_q``: Hann windows of length Q sr / f, L1-normalised,
+``scale=True``) evaluated *directly at the original sample rate* as a strided GEMM instead of librosa's octave-wise
+resampling recursion -- and is checked against ``oracle/restate_hcqt.py``, a float64 restatement of the same definition
+(tests/test_gpu_hcqt.py).  Differences from librosa's own output are expected at the level of its resampling /
+``sparsity=0.01`` approximations; they have not been measured (they cannot be, here).
+``compute_annotation_array`` (:167-202) has no ``return`` in the reference (it yields ``None``) and no caller; it is not
+provided.
 """
 import ctypes
 
@@ -85,14 +91,174 @@ def compute_annotation_array_nooverlap(note_events, f_hcqt, fs_hcqt, annot_type=
     return out.cpu().numpy()
 
 
-def _needs_librosa(name):
-    def fn(*args, **kwargs):
-        raise NotImplementedError(
-            f"{name} wraps librosa.cqt / librosa.estimate_tuning (libdl/data_preprocessing/hcqt.py:31-164); librosa is not "
-            "part of this build and a re-implementation would have no executable reference to be pinned to (SURVEY 8 f4)")
-    fn.__name__ = name
-    return fn
+NOTE_C1_HZ = 32.70319566257483        # librosa.note_to_hz('C1'), the default fmin of the reference's signatures
 
 
-compute_hcqt = _needs_librosa("compute_hcqt")
-compute_efficient_hcqt = _needs_librosa("compute_efficient_hcqt")
+def _vp(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _as_device_audio(f_audio, device):
+    if not torch.cuda.is_available():
+        raise RuntimeError("multipitch_architectures_amd: the HCQT kernels need the GPU (no CPU fallback)")
+    device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    y = torch.as_tensor(np.ascontiguousarray(np.asarray(f_audio, dtype=np.float32))) if not torch.is_tensor(f_audio) \
+        else f_audio.to(torch.float32)
+    y = y.to(device).contiguous()
+    if y.dim() != 1 or y.numel() < 2:
+        raise ValueError("f_audio must be a mono signal (1-D, at least 2 samples)")
+    return y
+
+
+def _frames_times_basis(ypad, a_off, hop, basis, frames):
+    """C[frames][cols] = sum_k ypad[a_off + m hop + k] basis[k][cols]: the strided-A GEMM (overlapping frames, no copy)"""
+    K, cols = basis.shape
+    C = torch.empty((frames, cols), dtype=torch.float32, device=ypad.device)
+    rc = L.load().mpa_gemm(ctypes.c_void_p(ypad.data_ptr() + 4 * a_off), hop, 1, _vp(basis), cols, 1, None, _vp(C), cols, frames,
+                           cols, K, 0, 0, _stream())
+    L.check(rc, "mpa_gemm")
+    return C
+
+
+def estimate_tuning_device(y, sr=22050, n_fft=2048, bins_per_octave=12, resolution=0.01):
+    """librosa.estimate_tuning(y=..., bins_per_octave=...) as restated in oracle/restate_hcqt.py; y: device float32 tensor"""
+    lib = L.load()
+    n, hop, nb = y.numel(), n_fft // 4, n_fft // 2 + 1
+    ypad = torch.empty(n + n_fft, dtype=torch.float32, device=y.device)
+    L.check(lib.mpa_reflect_pad(_vp(y), n, n_fft // 2, n_fft // 2, _vp(ypad), _stream()), "mpa_reflect_pad")
+    frames = 1 + n // hop
+    basis = torch.empty((n_fft, 2 * nb), dtype=torch.float32, device=y.device)
+    L.check(lib.mpa_stft_basis(_vp(basis), n_fft, _stream()), "mpa_stft_basis")
+    C = _frames_times_basis(ypad, 0, hop, basis, frames)
+    S = torch.empty((frames, nb), dtype=torch.float32, device=y.device)
+    L.check(lib.mpa_complex_mag(_vp(C), _vp(S), frames * nb, _stream()), "mpa_complex_mag")
+    cap = frames * ((nb + 1) // 2)
+    pitch = torch.empty(cap, dtype=torch.float64, device=y.device)
+    mag = torch.empty(cap, dtype=torch.float32, device=y.device)
+    count = torch.zeros(1, dtype=torch.int32, device=y.device)
+    L.check(lib.mpa_piptrack(_vp(S), frames, nb, float(sr), n_fft, 150.0, 4000.0, 0.1, _vp(pitch), _vp(mag), _vp(count),
+                             _stream()), "mpa_piptrack")
+    n_c = int(count.item())
+    nbytes = int(lib.mpa_pitch_tuning_workspace(n_c))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=y.device)
+    tuning = torch.zeros(1, dtype=torch.float64, device=y.device)
+    L.check(lib.mpa_pitch_tuning(_vp(pitch), _vp(mag), n_c, int(bins_per_octave), float(resolution), _vp(tuning), _vp(ws), nbytes,
+                                 _stream()), "mpa_pitch_tuning")
+    return float(tuning.item())
+
+
+def _cqt_into(y, sr, hop, fmin, n_bins, bins_per_octave, out, members):
+    """| constant-Q transform | of y (direct evaluation) scattered into the HCQT tensor `out` [n_bins_out][frames][n_harm];
+    members: (first bin of the slice, harmonic index) per harmonic that takes `out.shape[0]` bins of this transform"""
+    lib = L.load()
+    n = y.numel()
+    frames = 1 + n // hop
+    Q = 1.0 / (2.0 ** (1.0 / bins_per_octave) - 1.0)
+    r4 = lambda v: (int(v) + 3) // 4 * 4
+    P = r4(np.ceil(Q * sr / fmin / 2.0) + 8)
+    ypad = torch.empty(n + 2 * P, dtype=torch.float32, device=y.device)
+    L.check(lib.mpa_reflect_pad(_vp(y), n, P, P, _vp(ypad), _stream()), "mpa_reflect_pad")
+    fac = (ctypes.c_int * len(members))(*[m[0] for m in members])
+    hid = (ctypes.c_int * len(members))(*[m[1] for m in members])
+    GROUP, COLS = 32, 64
+    for g0 in range(0, n_bins, GROUP):
+        nb = min(GROUP, n_bins - g0)
+        f0 = fmin * 2.0 ** (g0 / bins_per_octave)
+        half = int(np.ceil(Q * sr / f0 / 2.0)) + 2
+        K0 = r4(half)
+        K = (K0 + half + 31) // 32 * 32
+        basis = torch.empty((K, COLS), dtype=torch.float32, device=y.device)
+        L.check(lib.mpa_cqt_basis(_vp(basis), K, K0, COLS, float(f0), nb, int(bins_per_octave), float(sr), _stream()),
+                "mpa_cqt_basis")
+        C = _frames_times_basis(ypad, P - K0, hop, basis, frames)
+        L.check(lib.mpa_cqt_mag_scatter(_vp(C), frames, COLS, nb, g0, _vp(out), out.shape[0], out.shape[2], fac, hid,
+                                        len(members), _stream()), "mpa_cqt_mag_scatter")
+
+
+def efficient_hcqt_device(f_audio, fs=22050, fmin=NOTE_C1_HZ, fs_hcqt_target=91, bins_per_octave=60, num_octaves=6,
+                          num_harmonics=5, num_subharmonics=1, center_bins=True, device=None, tuning=None):
+    """compute_efficient_hcqt with the result left on the GPU: (float32 tensor (n_bins, n_frames, harmonics), fs_hcqt, hop)"""
+    y = _as_device_audio(f_audio, device)
+    eps = np.finfo(float).eps
+    num_octaves_eff = num_octaves + np.ceil(np.log2((num_subharmonics + 1)) + np.log2((num_harmonics))).astype(int)   # :112
+    hopsize_cqt, fs_cqt = compute_hopsize_cqt(fs_hcqt_target, fs=fs, num_octaves=num_octaves_eff)
+    fs_hcqt = fs / hopsize_cqt
+    assert np.mod(bins_per_octave, 12) == 0, 'Error: bins_per_octave no multiple of 12'
+    bins_per_semitone = int(bins_per_octave / 12)
+    if center_bins:
+        fmin = fmin / 2 ** ((bins_per_semitone - 1) / (2 * bins_per_octave))
+    tuning_est = estimate_tuning_device(y, sr=fs, bins_per_octave=bins_per_octave) if tuning is None else float(tuning)
+    fmin_tuned = fmin * 2 ** (tuning_est / bins_per_octave)
+    n_frames = np.floor(y.numel() / hopsize_cqt).astype(int) + 1
+    n_bins = bins_per_octave * num_octaves
+    f_hcqt = torch.zeros((n_bins, int(n_frames), num_harmonics + num_subharmonics), dtype=torch.float32, device=y.device)
+    # which harmonics share a CQT (hcqt.py:130-147, kept line by line)
+    list_harmonics = [1 / (n_sh + 1) for n_sh in range(num_subharmonics, 0, -1)] + [n_ha for n_ha in range(1, num_harmonics + 1)]
+    base_harmonics = np.zeros((len(list_harmonics)))
+    computed_harmonics = np.zeros((len(list_harmonics)))
+    base_harmonics[0] = 1 / (num_subharmonics + 1)
+    computed_harmonics[0] = 1
+    for n_h in range(1, len(list_harmonics)):
+        harmonic = list_harmonics[n_h]
+        n_base = 0
+        while computed_harmonics[n_h] < eps:
+            base = base_harmonics[n_base]
+            if base == 0:
+                base_harmonics[n_h] = list_harmonics[n_h]
+                computed_harmonics[n_h] = 1
+            elif np.mod(np.log2(harmonic / base), 1) == 0:
+                base_harmonics[n_h] = base
+                computed_harmonics[n_h] = 1
+            else:
+                n_base += 1
+    for base_h in np.unique(base_harmonics):
+        fmin_h = fmin_tuned * base_h
+        all_harmonics = np.where(base_harmonics == base_h)[0]
+        max_harmonic = np.max(all_harmonics)
+        num_add_octaves = int(np.ceil(np.log2(list_harmonics[max_harmonic] / base_h)))
+        n_bins_curr = (num_octaves + num_add_octaves) * bins_per_octave
+        members = [(int(np.log2(list_harmonics[h] / base_h).astype(int)) * bins_per_octave, int(h)) for h in all_harmonics]
+        _cqt_into(y, fs, hopsize_cqt, fmin_h, n_bins_curr, bins_per_octave, f_hcqt, members)
+    return f_hcqt, fs_hcqt, hopsize_cqt
+
+
+def compute_efficient_hcqt(f_audio, fs=22050, fmin=NOTE_C1_HZ, fs_hcqt_target=91, bins_per_octave=60, num_octaves=6,
+                           num_harmonics=5, num_subharmonics=1, center_bins=True):
+    """ Computes an HCQT in an efficient way using the same CQT for multiple-of-two harmonics (hcqt.py:89-164).
+    PARITY UNPINNED (module docstring).
+
+    Returns:
+        f_hcqt:            HCQT tensor (numpy float64), dimensions "#pitch_bins * #time_frames * #(sub)harmonics"
+        fs_hcqt:           resulting HCQT frame rate in Hz
+        hopsize_hcqt:      resulting HCQT hopsize in samples
+    """
+    f_hcqt, fs_hcqt, hop = efficient_hcqt_device(f_audio, fs, fmin, fs_hcqt_target, bins_per_octave, num_octaves,
+                                                 num_harmonics, num_subharmonics, center_bins)
+    return f_hcqt.cpu().numpy().astype(np.float64), fs_hcqt, hop
+
+
+def compute_hcqt(f_audio, fs=22050, fmin=NOTE_C1_HZ, fs_hcqt_target=91, bins_per_octave=60, num_octaves=6, num_harmonics=5,
+                 num_subharmonics=1, center_bins=True):
+    """ Computes a standard HCQT with one individual CQT for each (sub)harmonic (hcqt.py:31-86).  PARITY UNPINNED. """
+    y = _as_device_audio(f_audio, None)
+    hopsize_cqt, fs_cqt = compute_hopsize_cqt(fs_hcqt_target, fs=fs, num_octaves=num_octaves)
+    fs_hcqt = fs / hopsize_cqt
+    n_bins = num_octaves * bins_per_octave
+    assert np.mod(bins_per_octave, 12) == 0, 'Error: bins_per_octave no multiple of 12'
+    bins_per_semitone = int(bins_per_octave / 12)
+    if center_bins:
+        fmin = fmin / 2 ** ((bins_per_semitone - 1) / (2 * bins_per_octave))
+    tuning_est = estimate_tuning_device(y, sr=fs, bins_per_octave=bins_per_octave)
+    fmin_tuned = fmin * 2 ** (tuning_est / bins_per_octave)
+    n_frames = 1 + y.numel() // hopsize_cqt
+    f_hcqt = torch.zeros((n_bins, n_frames, num_harmonics + num_subharmonics), dtype=torch.float32, device=y.device)
+    _cqt_into(y, fs, hopsize_cqt, fmin_tuned, n_bins, bins_per_octave, f_hcqt, [(0, num_subharmonics)])
+    for n_ha in range(2, num_harmonics + 1):
+        _cqt_into(y, fs, hopsize_cqt, n_ha * fmin_tuned, n_bins, bins_per_octave, f_hcqt, [(0, num_subharmonics + n_ha - 1)])
+    for n_hs in range(1, num_subharmonics + 1):
+        _cqt_into(y, fs, hopsize_cqt, fmin_tuned / (n_hs + 1), n_bins, bins_per_octave, f_hcqt, [(0, num_subharmonics - n_hs)])
+    return f_hcqt.cpu().numpy().astype(np.float64), fs_hcqt, hopsize_cqt
