@@ -213,6 +213,37 @@ def eval_measures_probe(with_cpu, n_frames=20000):
     return res
 
 
+def hcqt_probe(with_cpu, seconds=30.0):
+    """audio -> HCQT (6 harmonics x 216 bins, 43 frames/s: the reference's feature settings,
+    01_precompute_features.ipynb cell 5) on the GPU, the signal resident in HBM.  Parity unpinned (librosa absent): see
+    DESIGN.md 6b."""
+    import numpy as np
+    from multipitch_architectures_amd.data_preprocessing import efficient_hcqt_device
+    sr = 22050
+    rng = np.random.default_rng(5)
+    t = np.arange(int(seconds * sr)) / sr
+    y = sum(a * np.sin(2 * np.pi * f * t) for f, a in ((220.0, 0.4), (277.2, 0.3), (329.6, 0.3), (440.0, 0.2)))
+    y = torch.from_numpy((y + 0.01 * rng.standard_normal(len(t))).astype(np.float32)).cuda()
+    kw = dict(fs=sr, fs_hcqt_target=50, bins_per_octave=36, num_octaves=6, num_harmonics=5, num_subharmonics=1)
+    efficient_hcqt_device(y, **kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    H, fs_h, hop = efficient_hcqt_device(y, **kw)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = {"audio_seconds": seconds, "wall_s": dt, "audio_seconds_per_s": seconds / dt, "frames": int(H.shape[1]),
+           "shape": list(H.shape), "parity": "unpinned (librosa absent; checked against oracle/restate_hcqt.py only)"}
+    if with_cpu:
+        from oracle import restate_hcqt as RH                       # checker timed as the CPU baseline, never shipped
+        ys = y[: 2 * sr].cpu().numpy().astype(np.float64)
+        t0 = time.perf_counter()
+        RH.efficient_hcqt(ys, **kw)
+        d2 = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": 2.0 / d2, "unit": "audio seconds/s", "cores": 1, "kind": "port",
+                               "sample": "2 s of audio, numpy float64 restatement (direct filter bank, one core)"}
+    return res
+
+
 def segment_inference_probe(model, n_frames=2000, segment=100):
     """whole-recording inference, the reference's loop (one 75-frame patch per output frame,
     exp126a...py:427-443) next to the opt-in segment-wise path (windows of segment+74 frames, `segment` frames per
@@ -438,12 +469,17 @@ def main():
         # HBM bytes per launch of that kernel and its MFMA-pipe busy fraction from separate rocprofv3 --pmc passes
         # (scratch/pmc_passes.sh -> scratch/pmc_summary.py -> profiles/); only valid for the configuration they were
         # collected on
-        traffic = mfma_busy = None
-        for tfile in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-            tfile = os.path.join(ROOT, "profiles", tfile)
-            if os.path.exists(tfile) and args.config == "SAUnet:L" and B_loc == 256 and args.frames == 75 and not bfx:
+        traffic = mfma_busy = traffic_source = None
+        tfiles = ("r03_bf16x3_pmc_traffic.json",) if bfx else ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+        for tname in tfiles:
+            tfile = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tfile) and args.config == "SAUnet:L" and B_loc == 256 and args.frames == 75:
                 tj = json.load(open(tfile))
                 traffic, mfma_busy = tj["traffic_bytes"], tj.get("mfma_busy")
+                # not measured in this run: counters come from separate rocprofv3 --pmc passes (the pool forbids combining
+                # them with anything else); the stamp says which file and which commit's kernels they describe
+                traffic_source = {"file": "profiles/" + tname, "commit": tj.get("commit"), "kernel": tj.get("kernel"),
+                                  "note": "separate rocprofv3 --pmc passes (scratch/pmc_passes.sh), not this run"}
                 break
         achieved = kflops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
         out = {
@@ -462,6 +498,7 @@ def main():
                        "frames": args.frames, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "mfma_busy": mfma_busy,
+                         "traffic_source": traffic_source,
                          "peak_note": ("dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per split-bf16 product; the launch "
                                        "includes the operand-split kernel in front of the convolution") if bfx else
                                       "dense fp32-input MFMA peak",
@@ -491,6 +528,7 @@ def main():
             out["patch_extraction"] = patch_extraction_probe(B_loc, not args.no_cpu_baseline)
             out["eval_measures"] = eval_measures_probe(not args.no_cpu_baseline)
             out["segment_inference"] = segment_inference_probe(model)
+            out["hcqt_frontend"] = hcqt_probe(not args.no_cpu_baseline)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dp:

@@ -2,9 +2,17 @@
    <out>_pmc_sq_summary.csv   per kernel: dispatches, mean counters, MFMA-pipe busy fraction, wave-state shares
    <out>_pmc_hbm_summary.csv  per kernel: mean FETCH_SIZE / WRITE_SIZE (KB) per dispatch, corrected traffic
    <out>_pmc_traffic.json     the roofline kernel of bench.py (largest-grid dispatch of the 16->128 forward)
-usage: python scratch/pmc_summary.py <tag> <out prefix, e.g. profiles/r02>   (run where gpurun_out/pmc_<tag>_* exist)"""
-import collections, csv, glob, json, os, re, sys
+usage: python scratch/pmc_summary.py <tag> <out prefix, e.g. profiles/r02> [kernel name prefix of the roofline kernel]
+(run where gpurun_out/pmc_<tag>_* exist).  The traffic file is stamped with the commit of the tree the passes ran on
+(MPA_COMMIT in the environment, else `git rev-parse HEAD`)."""
+import collections, csv, glob, json, os, re, subprocess, sys
 tag, out = sys.argv[1], sys.argv[2]
+roof_prefix = sys.argv[3] if len(sys.argv) > 3 else "conv_fwd_kernel<2, 12, 15"
+try:
+    commit = os.environ.get("MPA_COMMIT") or subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                                                            cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip()
+except Exception:       # noqa: BLE001
+    commit = None
 root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
 
 def load(part):
@@ -64,7 +72,7 @@ with open(out + "_pmc_hbm_summary.csv", "w") as f:
         fm, wm = (fs / fn if fn else 0.0), (ws / wn if wn else 0.0)
         w.writerow([k[0], k[1], max(fn, wn), f"{fm:.1f}", f"{wm:.1f}", f"{2 * fm * 1024 + wm * 1024:.0f}"])
 # the roofline kernel: 16->128 15x15 forward = the conv_fwd_kernel<2, 12, 15...> dispatches with the largest grid
-cand = [k for k in keys if k[0].startswith("conv_fwd_kernel<2, 12, 15")]
+cand = [k for k in keys if k[0].startswith(roof_prefix)]
 if cand:
     k = max(cand, key=lambda k: k[1])
     fn, fs = hb["FETCH_SIZE"][k]; wn, ws = hb["WRITE_SIZE"][k]
@@ -75,6 +83,8 @@ if cand:
                                    "MI355X_MICROARCH.md 'HBM')",
                "traffic_bytes": 2 * fm * 1024 + wm * 1024,
                "mfma_busy": sqk[0][5] if sqk else None,
+               "lds_bank_conflict_per_idx_active": sqk[0][9] if sqk else None,
+               "commit": commit,
                "source": f"gpurun_out/pmc_{tag}_fetch, pmc_{tag}_write, pmc_{tag}_sq (separate --pmc passes with --kernel-trace "
                          f"only; mean over {fn} dispatches)"}, open(out + "_pmc_traffic.json", "w"), indent=1)
 print(open(out + "_pmc_sq_summary.csv").read()[:3000])
