@@ -136,6 +136,10 @@ F64_CASES = [c for c in CASES if "y64" in load_golden(*c).files]
 # (tiny:SAUnet, B=50) is left to the fp32 tests: its float64 forward alone takes >1 min on 8 cores, and B=25 already pins
 # the batch-axis attention in float64 (forward *and* gradients)
 F64_SKIP = {("tiny:SAUnet", 50, 75)}
+# the batch-32 train goldens added in round 3 (one per family) exist for the tight fp32 gradient floor on the GPU; their
+# float64 pass costs 20-40 s each on 8 cores and pins nothing the batch-2 / batch-8 cases of the same families do not pin
+# already -- tiny:Unet keeps it (the suite has to run in a few minutes)
+F64_SKIP |= {(n, 32, 75) for n in ("tiny:CNN", "tiny:DRCNN", "tiny:SAUnet", "tiny:SAUSnet", "tiny:BLUnet", "tiny:PUnet")}
 
 
 @pytest.mark.parametrize("case", [c for c in F64_CASES if c not in SLOW and c not in F64_SKIP
