@@ -223,6 +223,13 @@ int mpa_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float* Bm, int6
 int mpa_gemm_batched(int nbatch, const float* const* A, int64_t lda_m, int64_t lda_k, const float* const* B, int64_t ldb_k,
                      int64_t ldb_n, const float* const* bias /*nullable*/, float* const* C, int64_t ldc, int M, int N, int K,
                      int shared_c, int act, void* stream);
+/* opt-in split-bf16 variant of mpa_gemm (hi*hi + hi*lo + lo*hi on bf16 MFMA, fp32 accumulation: conv_bf16x3.hip says what
+ * the mode trades): 16-byte aligned operands with unit stride along k or along the other dimension, K % 32 == 0; otherwise
+ * mpa_gemm_bf16x3_supported returns 0 / mpa_gemm_bf16x3 MPA_ERR_UNSUPPORTED and the caller stays on mpa_gemm               */
+int mpa_gemm_bf16x3_supported(const float* A, int64_t lda_m, int64_t lda_k, const float* Bm, int64_t ldb_k, int64_t ldb_n, int M,
+                              int N, int K);
+int mpa_gemm_bf16x3(const float* A, int64_t lda_m, int64_t lda_k, const float* Bm, int64_t ldb_k, int64_t ldb_n,
+                    const float* bias, float* C, int64_t ldc, int M, int N, int K, int accumulate, int act, void* stream);
 /* column sums of a (rows, N) matrix (Linear bias gradients) */
 int mpa_colsum(const float* x, float* out, int64_t rows, int N, int accumulate, void* stream);
 

@@ -117,6 +117,8 @@ struct BfxParams {
   int B, C8, H, W, Cout, OH, OW, QN, ph, pw;
   int tilesY, tilesX, coTiles, nTilesAll, NW, act;
   float slope;
+  int dbg;                   // diagnostics (env MPA_BFX_DEBUG): 1 = stage the input tile once, 2 = + the filter slab once,
+                             // 3 = + skip the MFMA sweep (staging / synchronisation skeleton only); results are wrong
 };
 
 template <int KH, int R>
@@ -188,8 +190,9 @@ __global__ __launch_bounds__(512) void conv_bfx_kernel(const BfxParams p) {
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                         // every wave holds the slab in registers: its buffer is free
-      if (s + 1 < nslab) stage_a(s + 1);                    // ... and the next slab streams in behind the MFMAs
+      if (s + 1 < nslab && p.dbg < 2) stage_a(s + 1);       // ... and the next slab streams in behind the MFMAs
       const uint4* xb = lds_x + xlane + 4 * q;
+      if (p.dbg == 3) continue;
       // input row d+1 is requested before the MFMAs of row d are issued: its LDS latency hides behind them
       bf16x8 bh = __builtin_bit_cast(bf16x8, xb[0]);
       bf16x8 bl = __builtin_bit_cast(bf16x8, xb[BFX_PX]);
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(512) void conv_bfx_kernel(const BfxParams p) {
     }
     if (chunk + 1 < p.C8) {
       __builtin_amdgcn_s_barrier();                         // every wave is done with this chunk's input tile
-      stage_x(chunk + 1);
+      if (p.dbg < 1) stage_x(chunk + 1);
     }
   }
 
@@ -327,6 +330,7 @@ int bfx_launch(const BfxGeom& g, int B, const void* xs, const void* wp, const fl
   p.QN = pl.QN; p.ph = g.ph; p.pw = g.pw;
   p.tilesY = pl.tilesY; p.tilesX = pl.tilesX; p.coTiles = pl.coTiles; p.nTilesAll = B * pl.tilesY * pl.tilesX;
   p.NW = pl.NW; p.act = act; p.slope = slope;
+  { const char* e = getenv("MPA_BFX_DEBUG"); p.dbg = e ? atoi(e) : 0; }
   const dim3 grid((unsigned)(mpa_cdiv(p.nTilesAll, 8) * 8 * pl.coTiles));
   static bool attr = false;
   if (!attr) {

@@ -327,6 +327,154 @@ int gemm_impl(GemmParams p, int nbatch, int shared_c, hipStream_t s) {
   return mpa_launch_status();
 }
 
+
+// ------------------------------------------------------------------------------------------------ split-bf16 GEMM (opt-in)
+// The same products with every fp32 operand carried as hi + lo bf16 halves, hi*hi + hi*lo + lo*hi on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation (conv_bf16x3.hip: what the mode trades).  128 x 128 tile, BK = 32, 2 x 2
+// waves of 4 x 4 MFMA tiles.  Threads 0..127 stage the A tile, 128..255 the B tile: 8 float4 loads each (a row's 32
+// consecutive k for k-contiguous operands; an r-quad's 8 consecutive k rows for r-contiguous ones -- the transposition
+// happens in registers), split into bf16 hi / lo and written as 16-byte granules (8 consecutive k of one row) into the
+// image [k octet][hi|lo][row]: fragment reads are conflict-free ds_read_b128 for either source layout.
+typedef __bf16 bf16x8_g __attribute__((ext_vector_type(8)));
+
+struct BfxTile { float4 v[8]; };
+
+// operand tile rows [r0, r0+128) x k [k0, k0+32): fast path only (16-byte aligned, unit stride along k or along r)
+__device__ __forceinline__ void bfx_tile_load(BfxTile& t, const float* __restrict__ src, long ld_r, long ld_k, int r0, int k0,
+                                              int Rlim, int u) {
+  if (ld_k == 1) {                         // thread u owns row u: 32 consecutive k
+    const int r = min(r0 + u, Rlim - 1);
+    const float4* ptr = reinterpret_cast<const float4*>(src + (long)r * ld_r + k0);
+    const bool ok = r0 + u < Rlim;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float4 x = ptr[j];
+      t.v[j] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  } else {                                 // thread u owns r-quad u & 31 and k octet u >> 5: 8 k rows of 4 consecutive r
+    const int q = u & 31, o = u >> 5;
+    const int r = r0 + 4 * q;
+    const bool ok = r + 3 < Rlim;
+    const int rc = ok ? r : max(0, min(r, Rlim - 4));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float* ptr = src + (long)(k0 + 8 * o + j) * ld_k + rc;
+      float4 x = *reinterpret_cast<const float4*>(ptr);
+      if (!ok) {                           // ragged edge: the quad straddles Rlim (Rlim % 4 == 0 is required, so it is all out)
+        x = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      t.v[j] = x;
+    }
+  }
+}
+
+__device__ __forceinline__ void bfx_granule_store(uint4* __restrict__ img, int oct, int row, const float (&x)[8]) {
+  bf16x8_g hi, lo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    hi[j] = (__bf16)x[j];
+    lo[j] = (__bf16)(x[j] - (float)hi[j]);
+  }
+  img[(oct * 2 + 0) * 128 + row] = __builtin_bit_cast(uint4, hi);
+  img[(oct * 2 + 1) * 128 + row] = __builtin_bit_cast(uint4, lo);
+}
+
+__device__ __forceinline__ void bfx_tile_store(const BfxTile& t, uint4* __restrict__ img, long ld_k, int u) {
+  if (ld_k == 1) {
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const float x[8] = {t.v[2 * o].x, t.v[2 * o].y, t.v[2 * o].z, t.v[2 * o].w,
+                          t.v[2 * o + 1].x, t.v[2 * o + 1].y, t.v[2 * o + 1].z, t.v[2 * o + 1].w};
+      bfx_granule_store(img, o, u, x);
+    }
+  } else {
+    const int q = u & 31, o = u >> 5;
+    const float x0[8] = {t.v[0].x, t.v[1].x, t.v[2].x, t.v[3].x, t.v[4].x, t.v[5].x, t.v[6].x, t.v[7].x};
+    const float x1[8] = {t.v[0].y, t.v[1].y, t.v[2].y, t.v[3].y, t.v[4].y, t.v[5].y, t.v[6].y, t.v[7].y};
+    const float x2[8] = {t.v[0].z, t.v[1].z, t.v[2].z, t.v[3].z, t.v[4].z, t.v[5].z, t.v[6].z, t.v[7].z};
+    const float x3[8] = {t.v[0].w, t.v[1].w, t.v[2].w, t.v[3].w, t.v[4].w, t.v[5].w, t.v[6].w, t.v[7].w};
+    bfx_granule_store(img, o, 4 * q + 0, x0);
+    bfx_granule_store(img, o, 4 * q + 1, x1);
+    bfx_granule_store(img, o, 4 * q + 2, x2);
+    bfx_granule_store(img, o, 4 * q + 3, x3);
+  }
+}
+
+__global__ __launch_bounds__(256) void gemm_bfx_kernel(const GemmParams p) {
+  __shared__ __attribute__((aligned(16))) uint4 As[1024];
+  __shared__ __attribute__((aligned(16))) uint4 Bs[1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int g = lane >> 4, l16 = lane & 15;
+  const bool stage_a = tid < 128;
+  const int u = tid & 127;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool splitk = gridDim.z > 1;
+  const int kbeg = blockIdx.z * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
+  BfxTile t;
+  auto load = [&](int k0) {
+    if (stage_a) bfx_tile_load(t, p.A, p.lda_m, p.lda_k, m0, k0, p.M, u);
+    else bfx_tile_load(t, p.B, p.ldb_n, p.ldb_k, n0, k0, p.N, u);
+  };
+  load(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += 32) {
+    __syncthreads();
+    if (stage_a) bfx_tile_store(t, As, p.lda_k, u);
+    else bfx_tile_store(t, Bs, p.ldb_k, u);
+    __syncthreads();
+    if (k0 + 32 < kend) load(k0 + 32);           // next k-tile's global loads fly behind this tile's MFMAs
+    bf16x8_g ah[4], al[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ah[i] = __builtin_bit_cast(bf16x8_g, As[(g * 2 + 0) * 128 + wm + i * 16 + l16]);
+      al[i] = __builtin_bit_cast(bf16x8_g, As[(g * 2 + 1) * 128 + wm + i * 16 + l16]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bf16x8_g bh = __builtin_bit_cast(bf16x8_g, Bs[(g * 2 + 0) * 128 + wn + j * 16 + l16]);
+      const bf16x8_g bl = __builtin_bit_cast(bf16x8_g, Bs[(g * 2 + 1) * 128 + wn + j * 16 + l16]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  // D[m = 4 g + r][n = l16]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn + j * 16 + l16;
+      if (n >= p.N) continue;
+      const float bv = (p.bias && blockIdx.z == 0) ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm + i * 16 + g * 4 + r;
+        if (m >= p.M) continue;
+        const float v = acc[i][j][r] + bv;
+        float* c = p.C + (long)m * p.ldc + n;
+        if (splitk) { atomicAdd(c, v); continue; }
+        *c = mpa_apply_act(p.accumulate ? v + *c : v, p.act, 0.f);
+      }
+    }
+}
+
+bool gemm_bfx_ok(const float* A, long lda_m, long lda_k, const float* B, long ldb_k, long ldb_n, int M, int N, int K) {
+  auto opnd = [](const float* ptr, long ld_r, long ld_k, int R) {
+    if (reinterpret_cast<uintptr_t>(ptr) & 15) return false;
+    if (ld_k == 1) return ld_r % 4 == 0;
+    return ld_r == 1 && ld_k % 4 == 0 && R % 4 == 0 && R >= 4;
+  };
+  return K % 32 == 0 && K >= 32 && M >= 1 && N >= 1 && opnd(A, lda_m, lda_k, M) && opnd(B, ldb_n, ldb_k, N);
+}
+
 }  // namespace
 
 extern "C" int mpa_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float* Bm, int64_t ldb_k, int64_t ldb_n,
@@ -350,3 +498,33 @@ extern "C" int mpa_gemm_batched(int nbatch, const float* const* A, int64_t lda_m
   }
   return gemm_impl(p, nbatch, shared_c, (hipStream_t)stream);
 }
+
+// ---- opt-in split-bf16 variant (ops.set_conv_precision("bf16x3") routes the large nn.Linear / LSTM products here)
+extern "C" int mpa_gemm_bf16x3_supported(const float* A, int64_t lda_m, int64_t lda_k, const float* Bm, int64_t ldb_k,
+                                         int64_t ldb_n, int M, int N, int K) {
+  return (A && Bm && gemm_bfx_ok(A, (long)lda_m, (long)lda_k, Bm, (long)ldb_k, (long)ldb_n, M, N, K)) ? 1 : 0;
+}
+
+extern "C" int mpa_gemm_bf16x3(const float* A, int64_t lda_m, int64_t lda_k, const float* Bm, int64_t ldb_k, int64_t ldb_n,
+                               const float* bias, float* C, int64_t ldc, int M, int N, int K, int accumulate, int act,
+                               void* stream) {
+  if (!A || !Bm || !C || M <= 0 || N <= 0 || K <= 0) return MPA_ERR_ARG;
+  if (!gemm_bfx_ok(A, (long)lda_m, (long)lda_k, Bm, (long)ldb_k, (long)ldb_n, M, N, K)) return MPA_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  GemmParams p{A, Bm, bias, C, (long)lda_m, (long)lda_k, (long)ldb_k, (long)ldb_n, (long)ldc, M, N, K, accumulate, act, K};
+  const long blocks = mpa_cdiv(M, 128) * mpa_cdiv(N, 128);
+  int splits = 1;
+  if (act == MPA_ACT_NONE && blocks < 384) {                 // few tiles, long K (weight gradients): split K, atomic adds
+    splits = (int)std::min<long>(std::min<long>(32, 512 / blocks), K / 256);
+    if (splits < 1) splits = 1;
+  }
+  if (splits > 1) {
+    p.kchunk = (int)(mpa_cdiv(mpa_cdiv(K, splits), 32) * 32);
+    splits = (int)mpa_cdiv(K, p.kchunk);
+  }
+  if (splits > 1 && !accumulate)
+    if (mpa_zero2d_async(C, sizeof(float) * ldc, sizeof(float) * N, M, s) != MPA_OK) return MPA_ERR_LAUNCH;
+  MPA_LAUNCH(gemm_bfx_kernel, dim3((unsigned)mpa_cdiv(N, 128), (unsigned)mpa_cdiv(M, 128), (unsigned)splits), dim3(256), 0, s, p);
+  return mpa_launch_status();
+}
+

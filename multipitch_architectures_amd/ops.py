@@ -854,8 +854,16 @@ class _GemmKey:
         return self._k
 
 
+GEMM_BFX_MIN_WORK = 1 << 27        # products smaller than this stay on the exact kernel (launch-bound either way)
+
+
 def _gemm(A, lda_m, lda_k, Bm, ldb_k, ldb_n, bias, C, ldc, M, N, K, accumulate=0, act=ACT_NONE):
-    call = lambda: _lib().mpa_gemm(A, lda_m, lda_k, Bm, ldb_k, ldb_n, bias, C, ldc, M, N, K, accumulate, act, _s())
+    lib = _lib()
+    if (_Precision.conv == "bf16x3" and M * N * K >= GEMM_BFX_MIN_WORK and min(M, N) >= 64 and
+            lib.mpa_gemm_bf16x3_supported(A, lda_m, lda_k, Bm, ldb_k, ldb_n, M, N, K)):
+        call = lambda: lib.mpa_gemm_bf16x3(A, lda_m, lda_k, Bm, ldb_k, ldb_n, bias, C, ldc, M, N, K, accumulate, act, _s())
+    else:
+        call = lambda: lib.mpa_gemm(A, lda_m, lda_k, Bm, ldb_k, ldb_n, bias, C, ldc, M, N, K, accumulate, act, _s())
     if _Probe.match is not None:
         _chk(_probed("gemm", _GemmKey(M, N, K, int(lda_k == 1), int(ldb_k == 1), accumulate, act), call), "mpa_gemm")
     else:
