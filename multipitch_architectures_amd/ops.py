@@ -854,12 +854,14 @@ class _GemmKey:
         return self._k
 
 
-GEMM_BFX_MIN_WORK = 1 << 27        # products smaller than this stay on the exact kernel (launch-bound either way)
+# products the split-bf16 GEMM wins on (scratch/gemm_bfx_time.py): 128-wide tiles filled in both directions and enough k
+# steps to amortise the on-the-fly split; the rest stays on the exact kernel
+GEMM_BFX_MIN_WORK = 1 << 30
 
 
 def _gemm(A, lda_m, lda_k, Bm, ldb_k, ldb_n, bias, C, ldc, M, N, K, accumulate=0, act=ACT_NONE):
     lib = _lib()
-    if (_Precision.conv == "bf16x3" and M * N * K >= GEMM_BFX_MIN_WORK and min(M, N) >= 64 and
+    if (_Precision.conv == "bf16x3" and M * N * K >= GEMM_BFX_MIN_WORK and min(M, N) >= 128 and K >= 128 and
             lib.mpa_gemm_bf16x3_supported(A, lda_m, lda_k, Bm, ldb_k, ldb_n, M, N, K)):
         call = lambda: lib.mpa_gemm_bf16x3(A, lda_m, lda_k, Bm, ldb_k, ldb_n, bias, C, ldc, M, N, K, accumulate, act, _s())
     else:

@@ -119,3 +119,60 @@ def test_layers_without_a_bf16x3_kernel_keep_the_exact_path(dev):
     ops.set_conv_precision("f32")
     y0 = ops.conv2d(x.to(dev), w.to(dev), None, (1, 1), (1, 1)).cpu()
     assert torch.equal(y, y0)
+
+
+# ---------------------------------------------------------------------------------------------- split-bf16 GEMM (gemm.hip)
+# (M, N, K, A k-contiguous, B k-contiguous, bias, act, accumulate): the four operand layouts nn.Linear / the LSTM use
+# (forward x W^T, backward-data dy W, backward-weight dy^T x), ragged M / N tiles, split-K (few tiles, long K)
+GEMMS = [(256, 256, 512, True, True, True, ops.ACT_NONE, 0), (300, 200, 256, True, True, True, ops.ACT_RELU, 0),
+         (128, 384, 640, True, False, False, ops.ACT_NONE, 0), (512, 72, 9600, False, False, False, ops.ACT_NONE, 0),
+         (128, 128, 8192, False, True, False, ops.ACT_NONE, 1), (1000, 64, 96, True, True, True, ops.ACT_NONE, 1),
+         (68, 132, 2048, False, False, True, ops.ACT_NONE, 0)]
+
+
+@pytest.mark.parametrize("g", GEMMS, ids=lambda g: "-".join(str(int(v)) for v in g))
+def test_gemm_bf16x3_matches_float64(dev, g):
+    from multipitch_architectures_amd import _lib as L
+    M, N, K, a_kc, b_kc, has_bias, act, accumulate = g
+    gen = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=gen)
+    Bm = torch.randn(K, N, generator=gen)
+    bias = torch.randn(N, generator=gen) if has_bias else None
+    C0 = torch.randn(M, N, generator=gen)
+    ref = A.double() @ Bm.double() + (bias.double() if has_bias else 0.0) + (C0.double() if accumulate else 0.0)
+    if act == ops.ACT_RELU:
+        ref = ref.clamp_min(0)
+    Ad = (A if a_kc else A.t().contiguous()).to(dev)            # k-contiguous: (M, K) row-major; else stored (K, M)
+    Bd = (Bm.t().contiguous() if b_kc else Bm).to(dev)          # k-contiguous: stored (N, K); else (K, N) row-major
+    lda_m, lda_k = (K, 1) if a_kc else (1, M)
+    ldb_k, ldb_n = (1, K) if b_kc else (N, 1)
+    C = C0.clone().to(dev)
+    bd = bias.to(dev) if has_bias else None
+    lib = L.load()
+    import ctypes
+    p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.mpa_gemm_bf16x3_supported(p(Ad), lda_m, lda_k, p(Bd), ldb_k, ldb_n, M, N, K) == 1
+    rc = lib.mpa_gemm_bf16x3(p(Ad), lda_m, lda_k, p(Bd), ldb_k, ldb_n, p(bd), p(C), N, M, N, K, accumulate, act, s)
+    assert rc == 0
+    torch.cuda.synchronize()
+    err = (C.cpu().double() - ref).abs().max() / ref.abs().max()
+    assert float(err) <= 2e-5, float(err)
+    # and the exact kernel on the same operands is what it is compared with in the models
+    C2 = C0.clone().to(dev)
+    assert lib.mpa_gemm(p(Ad), lda_m, lda_k, p(Bd), ldb_k, ldb_n, p(bd), p(C2), N, M, N, K, accumulate, act, s) == 0
+    torch.cuda.synchronize()
+    assert float((C2.cpu().double() - ref).abs().max() / ref.abs().max()) <= 2e-5
+
+
+def test_gemm_bf16x3_refuses_what_it_cannot_tile(dev):
+    import ctypes
+    from multipitch_architectures_amd import _lib as L
+    lib = L.load()
+    A = torch.randn(64, 48, device=dev)
+    Bm = torch.randn(64, 48, device=dev)
+    C = torch.zeros(64, 64, device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert lib.mpa_gemm_bf16x3_supported(p(A), 48, 1, p(Bm), 1, 48, 64, 64, 48) == 0       # K % 32
+    assert lib.mpa_gemm_bf16x3(p(A), 48, 1, p(Bm), 1, 48, None, p(C), 64, 64, 64, 48, 0, 0, None) == -3
+    assert lib.mpa_gemm_bf16x3_supported(ctypes.c_void_p(A.data_ptr() + 4), 48, 1, p(Bm), 1, 48, 60, 64, 32) == 0  # alignment
