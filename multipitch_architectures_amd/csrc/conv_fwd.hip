@@ -480,9 +480,38 @@ struct PackParams {
   int CK, nChunks, COT, COTP, coTiles;
   int KWP;                         // > 0: tap-vector layout packed[cot][chunk][dy][ck][COT][KWP] (see fwd_kw_special)
   long total;
+  // head conv2 (conv_head.hip): packed[chunk][(kq * hNT + tap) * hMTT + mtile][lane 64], hAUw words per chunk;
+  // lane (i, kk) of m-tile mt holds A[16 mt + i][chunk * CK + 4 kq + kk][tap].  head 1: forward (row = cout, tap = 3 dy + dx),
+  // head 2: backward-data (row = 3 cin + dx, contraction channel = cout, tap = dy)
+  int head, hNT, hMTT;
+  long hAUw;
 };
 
+__device__ __forceinline__ void conv_pack_head_range(const PackParams& p, long first, long step) {
+  const long used = (long)(p.CK / 4) * p.hNT * p.hMTT * 64;
+  for (long i = first; i < p.total; i += step) {
+    const long chunk = i / p.hAUw;
+    long r = i - chunk * p.hAUw;
+    float v = 0.f;
+    if (r < used) {
+      const int lane = (int)(r & 63); r >>= 6;
+      const int mt = (int)(r % p.hMTT); r /= p.hMTT;
+      const int tap = (int)(r % p.hNT);
+      const int kq = (int)(r / p.hNT);
+      const int m = 16 * mt + (lane & 15), k = (int)chunk * p.CK + 4 * kq + (lane >> 4);
+      if (p.head == 1) {
+        if (m < p.Cout_w && k < p.Cin_w) v = p.w[((long)m * p.Cin_w + k) * 9 + tap];
+      } else {
+        const int ci = m / 3, dx = m - 3 * ci;
+        if (ci < p.Cin_w && k < p.Cout_w) v = p.w[(((long)k * p.Cin_w + ci) * 3 + tap) * 3 + dx];
+      }
+    }
+    p.wp[i] = v;
+  }
+}
+
 __device__ __forceinline__ void conv_pack_range(const PackParams& p, long first, long step) {
+  if (p.head) { conv_pack_head_range(p, first, step); return; }
   for (long i = first; i < p.total; i += step) {
     long r = i;
     int col, ck, dx;
@@ -540,6 +569,10 @@ extern "C" {
 
 int64_t mpa_conv2d_packed_floats(const mpa_conv_desc* d, int mode) {
   if (!d) return MPA_ERR_ARG;
+  if (mode == 0 || mode == 1) {
+    const HeadPlan hp = plan_head(d, mode);
+    if (hp.ok) return (int64_t)hp.nChunks * hp.AUw;
+  }
   FwdPlan pl;
   int kh = d->kh, kw = d->kw;
   if (mode == 0) {
@@ -589,6 +622,14 @@ static int pack_params(const mpa_conv_desc* d, int mode, const float* w, float* 
   p.w = w; p.wp = w_packed;
   p.Cout_w = d->Cout; p.Cin_w = d->Cin; p.kh_w = d->kh; p.kw_w = d->kw;
   p.mode = mode; p.xphase = 0;
+  if (mode == 0 || mode == 1) {
+    const HeadPlan hp = plan_head(d, mode);
+    if (hp.ok) {
+      p.head = mode + 1; p.hNT = hp.NT; p.hMTT = hp.MTT; p.hAUw = hp.AUw; p.CK = hp.CK;
+      p.total = (long)hp.nChunks * hp.AUw;
+      return MPA_OK;
+    }
+  }
   FwdPlan pl;
   if (mode == 0) {
     pl = plan_fwd(d->B, d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw);
@@ -647,6 +688,7 @@ int mpa_conv2d_fwd(const mpa_conv_desc* d, const float* x, const float* w_packed
   if (!d || !x || !w_packed || !y || d->B <= 0) return MPA_ERR_ARG;
   const int OH = (d->H + 2 * d->ph - d->kh) / d->sh + 1, OW = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
   if (OH <= 0 || OW <= 0) return MPA_ERR_ARG;
+  if (plan_head(d, 0).ok) return mpa_conv_head_fwd(d, x, w_packed, bias, y, act, slope, (hipStream_t)stream);
   return conv_fwd_impl(d->B, d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw, x, w_packed, bias,
                        y, act, slope, (long)d->Cout * OH * OW, (long)OH * OW, OW, 1, d->Cout, (hipStream_t)stream);
 }
@@ -670,6 +712,7 @@ int mpa_conv2d_fwd_stats(const mpa_conv_desc* d, const float* x, const float* w_
 
 int mpa_conv2d_bwd_data(const mpa_conv_desc* d, const float* dy, const float* w_packed, float* dx, void* stream) {
   if (!d || !dy || !w_packed || !dx || d->B <= 0) return MPA_ERR_ARG;
+  if (plan_head(d, 1).ok) return mpa_conv_head_bwd_data(d, dy, w_packed, dx, (hipStream_t)stream);
   BwdDataGeom g = bwd_data_geom(d);
   if (!g.ok) return MPA_ERR_UNSUPPORTED;
   const long inBS = (long)d->Cin * d->H * d->W, inCS = (long)d->H * d->W;
@@ -690,7 +733,21 @@ int mpa_conv2d_bwd_data(const mpa_conv_desc* d, const float* dy, const float* w_
 
 int mpa_conv2d_describe_plan(const mpa_conv_desc* d, int mode, char* buf, int buflen) {
   if (!d || !buf || buflen <= 0) return MPA_ERR_ARG;
+  if (mode == 0 || mode == 1) {
+    const HeadPlan hp = plan_head(d, mode);
+    if (hp.ok) {
+      snprintf(buf, buflen, "head_gemm<%d,%d,%d> rows=%d tiles=%d K=%d CK=%d chunks=%d taps=%d px/wg=%d tiles/img=%d XS=%d lds=%zuB",
+               hp.MT, hp.WM, hp.WN, hp.Mrows, hp.MTT, hp.K, hp.CK, hp.nChunks, hp.NT, hp.PXT, hp.tilesP, hp.XS, hp.lds_bytes);
+      return MPA_OK;
+    }
+  }
   if (mode == 2) {
+    const HeadWgPlan hw = plan_head_wgrad(d);
+    if (hw.ok) {
+      snprintf(buf, buflen, "head_wgrad<%d> coGroups=%d chGroups=%d S=%d items/slice=%ld segments=%dx%dpx rowblocks=%dx%d lds=%zuB",
+               hw.MT, hw.coGroups, hw.chGroups, hw.S, hw.itemsPer, hw.NCS, hw.SEG, hw.NRB, hw.RB, hw.lds_bytes);
+      return MPA_OK;
+    }
     Wg15Plan q = plan_wgrad15(d);
     if (q.ok) {
       int n = snprintf(buf, buflen, "wgrad15%s<%d,%d> COT=%d coTiles=%d ciGroups=%d tile=%dx%d (DP %d) tiles=%dx%d S=%d lds=%zuB",

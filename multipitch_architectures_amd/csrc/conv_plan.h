@@ -528,6 +528,149 @@ Wg15Plan plan_wgrad15(const mpa_conv_desc* d) {
   return pl;
 }
 
+// ------------------------------------------------------------------------------------------------ head conv2 (conv_head.hip)
+// nn.Conv2d(n0, n1, (3,3), stride (1,3), padding (1,0)) of every model's head (unet_cnns.py:538-543, basic_cnns.py:390-395).
+// The column stride equals the filter width, so output pixel p = oy*OW + ox of an image reads the input plane (flattened,
+// q = y*W + x) at 3p + (dy-1)*W + dx: linear in p.  All three passes are therefore plain GEMMs whose B operand is a
+// shifted, strided view of a contiguous slab -- no tile edges along a row, no 2-D halo:
+//   forward        y [co][p]        = sum_{ci,dy,dx} w[co][ci][dy][dx] * x [ci][3p + (dy-1)W + dx]
+//   backward-data  dx[ci][3p + dx]  = sum_{co,dy}    w[co][ci][dy][dx] * dy[co][p - (dy-1)OW]
+//   backward-weight dw[co][ci][dy][dx] = sum_{b,p}   dy[co][p] * x[ci][3p + (dy-1)W + dx]
+// Rows above / below the image are zero pages of the DMA staging.
+struct HeadPlan {
+  bool ok;
+  int mode;            // 0 forward, 1 backward-data
+  int MT, WM, NB, WN;  // wave tile: MT 16-row tiles x NB 16-pixel blocks; workgroup = WM x WN waves
+  int CK, nChunks;     // contraction channels per staged chunk
+  int NT;              // taps per contraction channel (9 / 3)
+  int K, Mrows, MTT;   // contraction channels, valid output rows (Cout / 3*Cin), WM*MT
+  int P, SL, SN, HALO; // pixels per image; source plane words; source words per pixel; halo words either side
+  int XS, PXT, tilesP; // slab channel stride (== 16 mod 32: conflict-free ds_read_b32); pixels per workgroup; tiles per image
+  long AUw;            // words of one packed filter chunk (multiple of 256 = one 64-lane 16-byte DMA)
+  size_t lds_bytes;
+};
+
+inline bool head_geom_ok(const mpa_conv_desc* d) {
+  return d->kh == 3 && d->kw == 3 && d->sh == 1 && d->sw == 3 && d->ph == 1 && d->pw == 0 && d->W % 12 == 0 && d->W >= 12 &&
+         d->H >= 1 && ((long)d->H * d->W) % 4 == 0 && !getenv("MPA_HEAD_OFF");
+}
+
+inline HeadPlan plan_head(const mpa_conv_desc* d, int mode) {
+  HeadPlan pl{};
+  pl.ok = false;
+  if (!head_geom_ok(d)) return pl;
+  const int OW = d->W / 3;
+  pl.mode = mode;
+  pl.P = d->H * OW;
+  pl.NB = 5;
+  if (mode == 0) {
+    pl.K = d->Cin; pl.Mrows = d->Cout; pl.NT = 9; pl.SN = 3; pl.HALO = d->W; pl.SL = d->H * d->W;
+    const int tiles = (int)mpa_cdiv(d->Cout, 16);
+    if (tiles < 4 || tiles > 14 || d->Cin < 16) return pl;
+    if (tiles <= 7) { pl.WM = 1; pl.MT = tiles; }
+    else { pl.WM = 2; pl.MT = (int)mpa_cdiv(tiles, 2); }
+    pl.WN = 4;
+    // one workgroup per 320 pixels and all couts: below ~4 workgroups per CU the generic forward kernel (smaller tiles, cout
+    // tiles in the grid) fills the chip better -- measured (scratch/head_time.py, 128 -> 80): 73 against 84 TFLOP/s at batch
+    // 32, 88 against 80 at batch 64, 108 against 102 at batch 256.  Backward-data and backward-weight win at every batch.
+    long min_wgs = 1024;
+    if (const char* e = getenv("MPA_HEAD_FWD_MIN_WGS")) min_wgs = atol(e);
+    if ((long)d->B * mpa_cdiv(pl.P, 4 * pl.NB * 16) < min_wgs) return pl;
+  } else {
+    pl.K = d->Cout; pl.Mrows = 3 * d->Cin; pl.NT = 3; pl.SN = 1; pl.HALO = OW; pl.SL = d->H * OW;
+    const int tiles = (int)mpa_cdiv(3 * d->Cin, 16);
+    if (d->Cout < 16) return pl;
+    if (tiles >= 8 && tiles <= 14) { pl.WM = 2; pl.MT = (int)mpa_cdiv(tiles, 2); pl.WN = 4; }
+    else if (tiles >= 17 && tiles <= 28) { pl.WM = 4; pl.MT = (int)mpa_cdiv(tiles, 4); pl.WN = 2; }
+    else return pl;
+  }
+  pl.MTT = pl.WM * pl.MT;
+  pl.PXT = pl.WN * pl.NB * 16;
+  pl.tilesP = (int)mpa_cdiv(pl.P, pl.PXT);
+  pl.XS = round_mod(pl.SN * pl.PXT + 2 * pl.HALO, 32, 16);
+  // channels per chunk: 4 when that makes room for two workgroups per CU (4-wave forward tiles: the second workgroup's
+  // MFMAs cover this one's staging burst and barrier: 111 against 101 TFLOP/s), else 8 if it fits, else 4
+  auto lds_of = [&](int ck) {
+    pl.CK = ck;
+    pl.AUw = mpa_cdiv((long)(ck / 4) * pl.NT * pl.MTT * 64, 256) * 256;
+    pl.lds_bytes = 2 * ((size_t)mpa_cdiv((long)ck * (pl.XS / 4), 64) * 256 + (size_t)pl.AUw) * 4;
+    return pl.lds_bytes;
+  };
+  int ck = 0;
+  if (const char* e = getenv("MPA_HEAD_CK")) ck = atoi(e) == 4 ? 4 : 8;
+  if (!ck) ck = (pl.WM * pl.WN == 4 && lds_of(4) <= 78 * 1024) ? 4 : 8;
+  if (lds_of(ck) > 150 * 1024) {
+    if (ck == 8 && lds_of(4) <= 150 * 1024) ck = 4;
+    else return pl;
+  }
+  lds_of(ck);
+  if (pl.CK < 4) return pl;
+  pl.nChunks = (int)mpa_cdiv(pl.K, pl.CK);
+  pl.ok = true;
+  return pl;
+}
+
+// backward-weight: a workgroup (4 waves x 16 input channels, MT cout tiles, all 9 taps in 36*MT accumulator registers) owns
+// work items (image, column segment of SEG output pixels, block of rows) and walks the rows of an item top to bottom with a
+// ring of three input-row segments in LDS: every input row is staged once and serves the three filter rows of the output
+// rows around it.  Partial sums per slice, reduced in a fixed order.
+struct HeadWgPlan {
+  bool ok;
+  int MT, coGroups, chGroups, S;   // cout tiles per workgroup (<= 5), cout groups, 64-channel groups, slices
+  int P, NCS, SEG, NRB, RB;        // pixels per image; column segments and their width; row blocks and their height
+  long items, itemsPer;            // work items (B * NCS * NRB), items per slice
+  int XPu, DPu, XUs, DUs;          // 16-byte units: X channel pitch, dY row pitch, one X ring slot, one dY buffer
+  size_t lds_bytes;
+};
+
+inline HeadWgPlan plan_head_wgrad(const mpa_conv_desc* d) {
+  HeadWgPlan pl{};
+  pl.ok = false;
+  if (!head_geom_ok(d) || d->Cin < 16 || d->Cout < 16) return pl;
+  const int OW = d->W / 3;
+  pl.P = d->H * OW;
+  const int tiles = (int)mpa_cdiv(d->Cout, 16);
+  pl.coGroups = (int)mpa_cdiv(tiles, 5);
+  pl.MT = (int)mpa_cdiv(tiles, pl.coGroups);
+  pl.chGroups = (int)mpa_cdiv(d->Cin, 64);
+  for (pl.NCS = 1; pl.NCS <= OW / 4; ++pl.NCS) {
+    if (OW % (4 * pl.NCS)) continue;
+    pl.SEG = OW / pl.NCS;
+    pl.XPu = 3 * pl.SEG / 4 + 1;
+    pl.DPu = pl.SEG / 4 + 1;
+    pl.XUs = (int)(mpa_cdiv(64L * pl.XPu, 64) * 64);
+    pl.DUs = (int)(mpa_cdiv(16L * pl.MT * pl.DPu, 64) * 64);
+    pl.lds_bytes = (size_t)(3 * pl.XUs + 2 * pl.DUs) * 16;
+    // (a wave stages a ring slot in at most 8 and a dY buffer in at most 6 DMA instructions: HEAD_WG_NX / _ND)
+    if (pl.lds_bytes <= 150 * 1024 && pl.XUs <= 8 * 256 && pl.DUs <= 6 * 256) break;
+  }
+  if (pl.NCS > OW / 4) return pl;
+  const long groups = (long)pl.coGroups * pl.chGroups;
+  const long want = std::max<long>(1, 256 / std::min<long>(groups, 256));       // slices that fill the chip once
+  // row blocks: as few as fill the chip evenly -- every block re-reads two halo rows (small batches need the split: 32 images
+  // x 2 segments are 64 items for 128 slices)
+  {
+    double best = -1.0;
+    pl.NRB = 1;
+    for (int n = 1; n <= std::min(d->H, 16); ++n) {
+      const int RB = (int)mpa_cdiv(d->H, n), nrb = (int)mpa_cdiv(d->H, RB);
+      if (nrb != n) continue;
+      const long items = (long)d->B * pl.NCS * nrb, S0 = std::min<long>(items, want), per = mpa_cdiv(items, S0), S1 = mpa_cdiv(items, per);
+      const double eff = (double)items / (double)(per * S1) * std::min(1.0, (double)(S1 * groups) / 256.0) / (1.0 + 2.0 / RB);
+      if (eff > best + 1e-3) { best = eff; pl.NRB = n; }
+    }
+  }
+  pl.RB = (int)mpa_cdiv(d->H, pl.NRB);
+  pl.NRB = (int)mpa_cdiv(d->H, pl.RB);
+  pl.items = (long)d->B * pl.NCS * pl.NRB;
+  long S = std::min<long>(pl.items, want);
+  if (const char* e = getenv("MPA_HEAD_WG_S")) { const long f = atol(e); if (f >= 1 && f <= pl.items) S = f; }
+  pl.itemsPer = mpa_cdiv(pl.items, S);
+  pl.S = (int)mpa_cdiv(pl.items, pl.itemsPer);
+  pl.ok = true;
+  return pl;
+}
+
 #ifdef MPA_PLAN_OWN_CDIV
 #undef mpa_cdiv
 #undef MPA_PLAN_OWN_CDIV

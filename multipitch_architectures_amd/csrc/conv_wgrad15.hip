@@ -504,6 +504,7 @@ extern "C" {
 
 int64_t mpa_conv2d_bwd_weight_workspace(const mpa_conv_desc* d) {
   if (!d) return MPA_ERR_ARG;
+  if (plan_head_wgrad(d).ok) return mpa_conv_head_wgrad_workspace(d);
   Wg15Plan p15 = plan_wgrad15(d);
   if (p15.ok) return (int64_t)p15.S * d->Cout * (d->Cin * 225 + 1) * 4;
   WgPlan pl = plan_wgrad(d);
@@ -514,6 +515,8 @@ int64_t mpa_conv2d_bwd_weight_workspace(const mpa_conv_desc* d) {
 int mpa_conv2d_bwd_weight(const mpa_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
                           void* workspace, int64_t workspace_bytes, void* stream) {
   if (!d || !x || !dy || !dw || d->B <= 0) return MPA_ERR_ARG;
+  if (plan_head_wgrad(d).ok)
+    return mpa_conv_head_bwd_weight(d, x, dy, dw, db, workspace, workspace_bytes, (hipStream_t)stream);
   Wg15Plan p15 = plan_wgrad15(d);
   if (p15.ok) {
     const int Ntot = d->Cin * 225;

@@ -15,7 +15,8 @@ opt = AdamW(model.parameters(), lr=1e-3, weight_decay=0.01); _bce = BCELoss()
 from multipitch_architectures_amd.losses import PolyphonyLoss
 _pl = PolyphonyLoss()
 loss_fn = lambda res, y: _pl(res[0], res[1], y) if isinstance(res, tuple) else _bce(res, y)
-x, y = synth_batch(B, 75); x, y = x.to(dev), y.to(dev)
+T = int(sys.argv[3]) if len(sys.argv) > 3 else 75
+x, y = synth_batch(B, T); x, y = x.to(dev), y.to(dev)
 def step():
     loss = loss_fn(model(x), y); opt.zero_grad(); loss.backward(); opt.step()
 step(); step()
@@ -32,5 +33,5 @@ for (k, kind), t in zip(keys, ms):
     rows.append((t - fl / 157.3e9, t, fl / t / 1e9, kind, k))
 tot = sum(r[1] for r in rows); ideal = sum(r[1] - r[0] for r in rows)
 print(f"conv total {tot:.1f} ms, MFMA-ideal {ideal:.1f} ms")
-for lost, t, tf, kind, k in sorted(rows, reverse=True)[:30]:
+for lost, t, tf, kind, k in sorted(rows, reverse=True)[:45]:
     print(f"lost {lost:6.2f} ms  {t:7.3f} ms {tf:6.1f} TF/s {kind:6s} Cin={k[1]:4d} {k[2]}x{k[3]} Cout={k[4]:4d} k={k[5]}x{k[6]} s={k[7]},{k[8]}")

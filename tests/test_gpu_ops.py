@@ -604,6 +604,7 @@ def test_conv_backward_weight_every_global_dy_kernel(dev, variant, geom, monkeyp
         pytest.skip("unaligned rows exist for the <2,8> variant only")
     monkeypatch.setenv("MPA_WG_GA", "force")
     monkeypatch.setenv("MPA_WG_VARIANT", str(variant))
+    monkeypatch.setenv("MPA_HEAD_OFF", "1")            # stride 3: the generic kernel under test, not conv_head.hip
     B, Cin, H, Cout, k = 2, 21, 7, 37, 3
     pad = (1, 1) if sw == 1 else (1, 0)
     d = L.ConvDesc(B, Cin, H, W, Cout, k, k, 1, sw, pad[0], pad[1])
