@@ -49,7 +49,7 @@ typedef struct mpa_conv_desc {
   int32_t sh, sw, ph, pw;   /* stride, zero padding               */
 } mpa_conv_desc;
 
-/* number of floats of the packed filter bank used by fwd (mode 0) / bwd-data (mode 1) */
+/* number of floats of the packed filter bank used by fwd (mode 0) / bwd-data (mode 1) / fwd with the cout remainder fold (mode 2) */
 int64_t mpa_conv2d_packed_floats(const mpa_conv_desc* d, int mode);
 /* repack (Cout,Cin,kh,kw) filters for fwd (mode 0) or, flipped+transposed, for bwd-data (mode 1) */
 int mpa_conv2d_pack(const mpa_conv_desc* d, int mode, const float* w, float* w_packed, void* stream);
@@ -61,6 +61,14 @@ int mpa_conv2d_pack(const mpa_conv_desc* d, int mode, const float* w, float* w_p
 int mpa_conv2d_pack_entry_bytes(void);
 int mpa_conv2d_pack_entry(const mpa_conv_desc* d, int mode, const float* w, float* w_packed, void* host_entry);
 int mpa_conv2d_pack_many(const void* device_table, int n, void* stream);
+/* Forward pass of a 15x15 stride-1 layer whose output channels are not a multiple of 16 (70 = 64 + 6, basic_cnns.py:371-387)
+ * as two launches into y: channels [0, C0) as an ordinary convolution, the R <= 8 remaining channels as V * R rows of one
+ * 16-row MFMA tile (V = 2 or 4 vertically adjacent output rows per channel).  w_packed from mpa_conv2d_pack(d, 2, ...)
+ * (mpa_conv2d_packed_floats(d, 2) floats).  mpa_conv2d_fold_supported: 1 when the layer qualifies.  Backward-data applies
+ * the same split by itself (mode 1 banks). */
+int mpa_conv2d_fold_supported(const mpa_conv_desc* d);
+int mpa_conv2d_fwd_folded(const mpa_conv_desc* d, const float* x, const float* w_packed, const float* bias, float* y, int act,
+                          float slope, void* stream);
 /* y = act(conv(x, w) + bias) ; bias may be NULL */
 int mpa_conv2d_fwd(const mpa_conv_desc* d, const float* x, const float* w_packed, const float* bias,
                    float* y, int act, float slope, void* stream);
@@ -73,7 +81,8 @@ int mpa_conv2d_fwd_stats(const mpa_conv_desc* d, const float* x, const float* w_
                          float* partials, void* stream);
 /* dx = conv_transpose(dy, w)  (w_packed from mode 1) */
 int mpa_conv2d_bwd_data(const mpa_conv_desc* d, const float* dy, const float* w_packed, float* dx, void* stream);
-/* human-readable tiling chosen for fwd (mode 0), bwd-data (1), bwd-weight (2) -- diagnostics / DESIGN.md tables */
+/* human-readable tiling chosen for fwd (mode 0), bwd-data (1), bwd-weight (2), fwd with the cout remainder fold (3) --
+ * diagnostics / DESIGN.md tables */
 int mpa_conv2d_describe_plan(const mpa_conv_desc* d, int mode, char* buf, int buflen);
 /* dw = sum_b,y,x dy * x ; db = sum dy (db may be NULL).  workspace bytes from the helper. */
 int64_t mpa_conv2d_bwd_weight_workspace(const mpa_conv_desc* d);

@@ -52,6 +52,8 @@ SIGNATURES = {
     "mpa_conv2d_pack_entry": (c_int, [_D, c_int, _P, _P, _P]),
     "mpa_conv2d_pack_many": (c_int, [_P, c_int, _P]),
     "mpa_conv2d_fwd": (c_int, [_D, _P, _P, _P, _P, c_int, c_float, _P]),
+    "mpa_conv2d_fold_supported": (c_int, [_D]),
+    "mpa_conv2d_fwd_folded": (c_int, [_D, _P, _P, _P, _P, c_int, c_float, _P]),
     "mpa_conv2d_fwd_stats_rows": (c_int64, [_D]),
     "mpa_conv2d_fwd_stats": (c_int, [_D, _P, _P, _P, _P, _P, _P]),
     "mpa_conv2d_bwd_data": (c_int, [_D, _P, _P, _P, _P]),

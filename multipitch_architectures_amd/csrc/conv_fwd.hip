@@ -359,7 +359,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
         const int co = cot * p.COT + nb * 16 + kq * 4 + r;
         if (co >= p.Cout) continue;
         float v = acc[nb][pb][r];
-        if (p.bias && blockIdx.z == 0) v += p.bias[co];
+        // (phase stores: the bias belongs to the channel the row maps to -- cout remainder fold of the forward pass)
+        if (p.bias && blockIdx.z == 0) v += p.bias[PH ? co / (p.outXmul * p.outYmul) : co];
         float* dst;
         if constexpr (!PH) {                  // plain NCHW store
           dst = p.y + (long)b * p.outBS + (long)co * p.outCS + (long)oy * p.outRS + ox;
@@ -470,25 +471,32 @@ int launch_fwd(const FwdPlan& pl, const ConvFwdParams& p, hipStream_t s) {
 //   mode 0 (forward)      : value = w[co][ci][dy][dx]
 //   mode 1 (backward-data): the derived conv has Cin' = Cout, Cout' = Cin (stride 1) or kw*Cin (stride == kernel
 //                           along W), value = w[ci'][co' % Cin][kh-1-dy][dxsel]
+struct PackDims {                  // one packed bank: dims of the conv that will consume it
+  int xphase;                      // strided-W backward (dx taken from co' / Cin)
+  int yphase;                      // V > 1: cout'' = c*V + v with the (flipped, for backward-data) filter shifted down by v rows
+  int CinP, CoutP, kh, kw;
+  int CK, nChunks, COT, COTP, coTiles;
+  int KWP;                         // > 0: tap-vector layout packed[cot][chunk][dy][ck][COT][KWP] (see fwd_kw_special)
+  int co_off;                      // first source channel of the bank's output rows (cout remainder fold: C0)
+  long total;
+};
+
 struct PackParams {
   const float* w;
   float* wp;
   int Cout_w, Cin_w, kh_w, kw_w;   // original filter dims
-  int mode, xphase;                // xphase: strided-W backward (dx taken from co' / Cin)
-  int yphase;                      // V > 1: cout'' = cin*V + v with the flipped filter shifted down by v rows
-  int CinP, CoutP, kh, kw;         // dims of the conv that will consume the packed filters
-  int CK, nChunks, COT, COTP, coTiles;
-  int KWP;                         // > 0: tap-vector layout packed[cot][chunk][dy][ck][COT][KWP] (see fwd_kw_special)
+  int mode;                        // 0 forward, 1 backward-data (flipped + transposed), 2 forward with the cout remainder fold
+  PackDims a, b;                   // b.total > 0: second bank behind the first (cout remainder fold: main channels, fold rows)
   long total;
   // head conv2 (conv_head.hip): packed[chunk][(kq * hNT + tap) * hMTT + mtile][lane 64], hAUw words per chunk;
   // lane (i, kk) of m-tile mt holds A[16 mt + i][chunk * CK + 4 kq + kk][tap].  head 1: forward (row = cout, tap = 3 dy + dx),
   // head 2: backward-data (row = 3 cin + dx, contraction channel = cout, tap = dy)
-  int head, hNT, hMTT;
+  int head, hNT, hMTT, hCK;
   long hAUw;
 };
 
 __device__ __forceinline__ void conv_pack_head_range(const PackParams& p, long first, long step) {
-  const long used = (long)(p.CK / 4) * p.hNT * p.hMTT * 64;
+  const long used = (long)(p.hCK / 4) * p.hNT * p.hMTT * 64;
   for (long i = first; i < p.total; i += step) {
     const long chunk = i / p.hAUw;
     long r = i - chunk * p.hAUw;
@@ -498,7 +506,7 @@ __device__ __forceinline__ void conv_pack_head_range(const PackParams& p, long f
       const int mt = (int)(r % p.hMTT); r /= p.hMTT;
       const int tap = (int)(r % p.hNT);
       const int kq = (int)(r / p.hNT);
-      const int m = 16 * mt + (lane & 15), k = (int)chunk * p.CK + 4 * kq + (lane >> 4);
+      const int m = 16 * mt + (lane & 15), k = (int)chunk * p.hCK + 4 * kq + (lane >> 4);
       if (p.head == 1) {
         if (m < p.Cout_w && k < p.Cin_w) v = p.w[((long)m * p.Cin_w + k) * 9 + tap];
       } else {
@@ -510,44 +518,51 @@ __device__ __forceinline__ void conv_pack_head_range(const PackParams& p, long f
   }
 }
 
+__device__ __forceinline__ float conv_pack_value(const PackParams& p, const PackDims& q, long r) {
+  int col, ck, dx;
+  if (q.KWP > 0) {
+    int pos = (int)(r % q.KWP); r /= q.KWP;
+    col = (int)(r % q.COTP); r /= q.COTP;
+    ck = (int)(r % q.CK); r /= q.CK;
+    // 16-tap rows: chunk g of the row sits at position (g + (col&15)>>2) & 3 -- undo the rotation to find the tap
+    if (q.KWP == 16) pos = ((((pos >> 2) - ((col & 15) >> 2)) & 3) << 2) | (pos & 3);
+    dx = pos;
+  } else {
+    col = (int)(r % q.COTP); r /= q.COTP;
+    ck = (int)(r % q.CK); r /= q.CK;
+    dx = (int)(r % q.kw); r /= q.kw;
+  }
+  const int dy = (int)(r % q.kh); r /= q.kh;
+  const int chunk = (int)(r % q.nChunks); r /= q.nChunks;
+  const int cot = (int)r;
+  const int co = cot * q.COT + col, ci = chunk * q.CK + ck;
+  float v = 0.f;
+  if (col < q.COT && co < q.CoutP && ci < q.CinP && dx < q.kw) {
+    if (p.mode != 1) {                 // forward: w[co][ci][dy][dx]; fold rows: channel co_off + co / V, filter shifted down by co % V
+      if (q.yphase > 1) {
+        const int cc = co / q.yphase, dyo = dy - (co - cc * q.yphase);
+        if (dyo >= 0 && dyo < p.kh_w) v = p.w[(((long)(q.co_off + cc) * p.Cin_w + ci) * p.kh_w + dyo) * p.kw_w + dx];
+      } else {
+        v = p.w[(((long)(q.co_off + co) * p.Cin_w + ci) * p.kh_w + dy) * p.kw_w + dx];
+      }
+    } else if (q.yphase > 1) {
+      const int cc = co / q.yphase, dyo = dy - (co - cc * q.yphase);
+      if (dyo >= 0 && dyo < p.kh_w)
+        v = p.w[(((long)ci * p.Cin_w + q.co_off + cc) * p.kh_w + (p.kh_w - 1 - dyo)) * p.kw_w + (p.kw_w - 1 - dx)];
+    } else if (!q.xphase) {
+      v = p.w[(((long)ci * p.Cin_w + q.co_off + co) * p.kh_w + (p.kh_w - 1 - dy)) * p.kw_w + (p.kw_w - 1 - dx)];
+    } else {
+      const int cc = co / p.kw_w, ph = co - cc * p.kw_w;    // cout' = cin*kw + dx phase (see the epilogue)
+      v = p.w[(((long)ci * p.Cin_w + cc) * p.kh_w + (p.kh_w - 1 - dy)) * p.kw_w + ph];
+    }
+  }
+  return v;
+}
+
 __device__ __forceinline__ void conv_pack_range(const PackParams& p, long first, long step) {
   if (p.head) { conv_pack_head_range(p, first, step); return; }
-  for (long i = first; i < p.total; i += step) {
-    long r = i;
-    int col, ck, dx;
-    if (p.KWP > 0) {
-      int pos = (int)(r % p.KWP); r /= p.KWP;
-      col = (int)(r % p.COTP); r /= p.COTP;
-      ck = (int)(r % p.CK); r /= p.CK;
-      // 16-tap rows: chunk g of the row sits at position (g + (col&15)>>2) & 3 -- undo the rotation to find the tap
-      if (p.KWP == 16) pos = ((((pos >> 2) - ((col & 15) >> 2)) & 3) << 2) | (pos & 3);
-      dx = pos;
-    } else {
-      col = (int)(r % p.COTP); r /= p.COTP;
-      ck = (int)(r % p.CK); r /= p.CK;
-      dx = (int)(r % p.kw); r /= p.kw;
-    }
-    const int dy = (int)(r % p.kh); r /= p.kh;
-    const int chunk = (int)(r % p.nChunks); r /= p.nChunks;
-    const int cot = (int)r;
-    const int co = cot * p.COT + col, ci = chunk * p.CK + ck;
-    float v = 0.f;
-    if (col < p.COT && co < p.CoutP && ci < p.CinP && dx < p.kw) {
-      if (p.mode == 0) {
-        v = p.w[(((long)co * p.Cin_w + ci) * p.kh_w + dy) * p.kw_w + dx];
-      } else if (p.yphase > 1) {
-        const int cc = co / p.yphase, dyo = dy - (co - cc * p.yphase);
-        if (dyo >= 0 && dyo < p.kh_w)
-          v = p.w[(((long)ci * p.Cin_w + cc) * p.kh_w + (p.kh_w - 1 - dyo)) * p.kw_w + (p.kw_w - 1 - dx)];
-      } else if (!p.xphase) {
-        v = p.w[(((long)ci * p.Cin_w + co) * p.kh_w + (p.kh_w - 1 - dy)) * p.kw_w + (p.kw_w - 1 - dx)];
-      } else {
-        const int cc = co / p.kw_w, q = co - cc * p.kw_w;    // cout' = cin*kw + dx phase (see the epilogue)
-        v = p.w[(((long)ci * p.Cin_w + cc) * p.kh_w + (p.kh_w - 1 - dy)) * p.kw_w + q];
-      }
-    }
-    p.wp[i] = v;
-  }
+  for (long i = first; i < p.total; i += step)
+    p.wp[i] = i < p.a.total ? conv_pack_value(p, p.a, i) : conv_pack_value(p, p.b, i - p.a.total);
 }
 
 __global__ void conv_pack_kernel(const PackParams p) {
@@ -567,27 +582,14 @@ __global__ void conv_pack_many_kernel(const PackParams* __restrict__ table) {
 // ------------------------------------------------------------------------------------------------ C ABI
 extern "C" {
 
+static int pack_params(const mpa_conv_desc* d, int mode, const float* w, float* w_packed, PackParams& p);
+
 int64_t mpa_conv2d_packed_floats(const mpa_conv_desc* d, int mode) {
   if (!d) return MPA_ERR_ARG;
-  if (mode == 0 || mode == 1) {
-    const HeadPlan hp = plan_head(d, mode);
-    if (hp.ok) return (int64_t)hp.nChunks * hp.AUw;
-  }
-  FwdPlan pl;
-  int kh = d->kh, kw = d->kw;
-  if (mode == 0) {
-    pl = plan_fwd(d->B, d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw);
-  } else {
-    BwdDataGeom g = bwd_data_geom(d);
-    if (!g.ok) return MPA_ERR_UNSUPPORTED;
-    pl = plan_bwd_data(d, g);
-    kh = g.kh; kw = g.kw;
-  }
-  if (!pl.ok) return MPA_ERR_UNSUPPORTED;
-  return (int64_t)pl.coTiles * pl.nChunks * kh * (pl.KWS ? pl.KWP : kw) * pl.CK * pl.COTP;
+  PackParams p{};
+  const int rc = pack_params(d, mode, nullptr, nullptr, p);
+  return rc ? rc : (int64_t)p.total;
 }
-
-static int pack_params(const mpa_conv_desc* d, int mode, const float* w, float* w_packed, PackParams& p);
 
 int mpa_conv2d_pack(const mpa_conv_desc* d, int mode, const float* w, float* w_packed, void* stream) {
   if (!d || !w || !w_packed) return MPA_ERR_ARG;
@@ -618,32 +620,85 @@ int mpa_conv2d_pack_many(const void* device_table, int n, void* stream) {
   return mpa_launch_status();
 }
 
+static long pack_dims(PackDims& q, const FwdPlan& pl, int CinP, int CoutP, int kh, int kw, int xphase, int yphase, int co_off) {
+  q.xphase = xphase; q.yphase = yphase; q.CinP = CinP; q.CoutP = CoutP; q.kh = kh; q.kw = kw;
+  q.CK = pl.CK; q.nChunks = pl.nChunks; q.COT = pl.COT; q.COTP = pl.COTP; q.coTiles = pl.coTiles;
+  q.KWP = pl.KWS ? pl.KWP : 0;
+  q.co_off = co_off;
+  q.total = (long)pl.coTiles * pl.nChunks * kh * (pl.KWS ? pl.KWP : kw) * pl.CK * pl.COTP;
+  return q.total;
+}
+
+// the two launches of a layer with the cout remainder fold (plan_fold): `main` = channels [0, C0), `fold` = V * R rows.
+// Forward (mode 2): the layer itself; backward-data (mode 1): the derived convolution (Cin' = Cout, Cout' = Cin).
+struct FoldLaunch {
+  bool ok;
+  FoldPlan f;
+  int Cin, H, W, kh, kw, ph, pw;    // the convolution the two launches split (forward: d's; backward-data: the derived one)
+  FwdPlan main, fold;
+};
+
+static FoldLaunch fold_launch(const mpa_conv_desc* d, int mode) {
+  FoldLaunch fl{};
+  fl.ok = false;
+  if (mode == 2) {
+    fl.f = plan_fold(d->Cout, d->kh, d->kw, d->sh, d->sw, d->H);
+    fl.Cin = d->Cin; fl.H = d->H; fl.W = d->W; fl.kh = d->kh; fl.kw = d->kw; fl.ph = d->ph; fl.pw = d->pw;
+  } else if (mode == 1) {
+    const BwdDataGeom g = bwd_data_geom(d);
+    if (!g.ok || g.xphase || g.yphase > 1) return fl;
+    fl.f = plan_fold(g.Cout, g.kh, g.kw, 1, 1, g.H);
+    fl.Cin = g.Cin; fl.H = g.H; fl.W = g.W; fl.kh = g.kh; fl.kw = g.kw; fl.ph = g.ph; fl.pw = g.pw;
+  } else {
+    return fl;
+  }
+  if (!fl.f.ok) return fl;
+  const int V = fl.f.V;
+  const int OH = fl.H + 2 * fl.ph - fl.kh + 1;
+  if (OH < 1) return fl;
+  fl.main = plan_fwd(d->B, fl.Cin, fl.H, fl.W, fl.f.C0, fl.kh, fl.kw, 1, 1, fl.ph, fl.pw);
+  fl.fold = plan_fwd(d->B, fl.Cin, fl.H + V - 1, fl.W, V * fl.f.R, fl.kh + V - 1, fl.kw, V, 1, fl.ph, fl.pw, false, true, 1);
+  fl.ok = fl.main.ok && fl.fold.ok;
+  return fl;
+}
+
 static int pack_params(const mpa_conv_desc* d, int mode, const float* w, float* w_packed, PackParams& p) {
   p.w = w; p.wp = w_packed;
   p.Cout_w = d->Cout; p.Cin_w = d->Cin; p.kh_w = d->kh; p.kw_w = d->kw;
-  p.mode = mode; p.xphase = 0;
+  p.mode = mode;
+  if (mode < 0 || mode > 2) return MPA_ERR_ARG;
   if (mode == 0 || mode == 1) {
     const HeadPlan hp = plan_head(d, mode);
     if (hp.ok) {
-      p.head = mode + 1; p.hNT = hp.NT; p.hMTT = hp.MTT; p.hAUw = hp.AUw; p.CK = hp.CK;
+      p.head = mode + 1; p.hNT = hp.NT; p.hMTT = hp.MTT; p.hAUw = hp.AUw; p.hCK = hp.CK;
       p.total = (long)hp.nChunks * hp.AUw;
       return MPA_OK;
     }
   }
+  if (mode != 0) {
+    const FoldLaunch fl = fold_launch(d, mode);
+    if (fl.ok) {
+      pack_dims(p.a, fl.main, fl.Cin, fl.f.C0, fl.kh, fl.kw, 0, 1, 0);
+      pack_dims(p.b, fl.fold, fl.Cin, fl.f.V * fl.f.R, fl.kh + fl.f.V - 1, fl.kw, 0, fl.f.V, fl.f.C0);
+      p.total = p.a.total + p.b.total;
+      return MPA_OK;
+    }
+    if (mode == 2) return MPA_ERR_UNSUPPORTED;
+  }
   FwdPlan pl;
   if (mode == 0) {
     pl = plan_fwd(d->B, d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw);
-    p.CinP = d->Cin; p.CoutP = d->Cout; p.kh = d->kh; p.kw = d->kw;
+    if (!pl.ok) return MPA_ERR_UNSUPPORTED;
+    pack_dims(p.a, pl, d->Cin, d->Cout, d->kh, d->kw, 0, 1, 0);
   } else {
     BwdDataGeom g = bwd_data_geom(d);
     if (!g.ok) return MPA_ERR_UNSUPPORTED;
     pl = plan_bwd_data(d, g);
-    p.CinP = g.Cin; p.CoutP = g.Cout; p.kh = g.kh; p.kw = g.kw; p.xphase = g.xphase ? 1 : 0; p.yphase = g.yphase;
+    if (!pl.ok) return MPA_ERR_UNSUPPORTED;
+    pack_dims(p.a, pl, g.Cin, g.Cout, g.kh, g.kw, g.xphase ? 1 : 0, g.yphase, 0);
   }
-  if (!pl.ok) return MPA_ERR_UNSUPPORTED;
-  p.CK = pl.CK; p.nChunks = pl.nChunks; p.COT = pl.COT; p.COTP = pl.COTP; p.coTiles = pl.coTiles;
-  p.KWP = pl.KWS ? pl.KWP : 0;
-  p.total = (long)pl.coTiles * pl.nChunks * p.kh * (pl.KWS ? pl.KWP : p.kw) * pl.CK * pl.COTP;
+  p.b.total = 0;
+  p.total = p.a.total;
   return MPA_OK;
 }
 
@@ -683,6 +738,35 @@ static int conv_fwd_impl(int B, int Cin, int H, int W, int Cout, int kh, int kw,
   return mpa_act_fwd(y, y, (int64_t)B * outBS, act, slope, s);
 }
 
+// the two launches of fold_launch(): src (x, or dy for backward-data), packed = [main bank][fold bank], dst with Ctot channels
+static int conv_folded_impl(const mpa_conv_desc* d, const FoldLaunch& fl, const float* src, const float* packed, const float* bias,
+                            float* dst, int act, float slope, hipStream_t s) {
+  const int OH = fl.H + 2 * fl.ph - fl.kh + 1, OW = fl.W + 2 * fl.pw - fl.kw + 1, V = fl.f.V;
+  const int Ctot = fl.f.C0 + fl.f.R;
+  const long outCS = (long)OH * OW, outBS = (long)Ctot * outCS;
+  PackDims a{};
+  const long a_total = pack_dims(a, fl.main, fl.Cin, fl.f.C0, fl.kh, fl.kw, 0, 1, 0);
+  int rc = conv_fwd_impl(d->B, fl.Cin, fl.H, fl.W, fl.f.C0, fl.kh, fl.kw, 1, 1, fl.ph, fl.pw, src, packed, bias, dst, act, slope,
+                         outBS, outCS, OW, 1, fl.f.C0, s);
+  if (rc) return rc;
+  return conv_fwd_impl(d->B, fl.Cin, fl.H, fl.W, V * fl.f.R, fl.kh + V - 1, fl.kw, V, 1, fl.ph, fl.pw, src, packed + a_total,
+                       bias ? bias + fl.f.C0 : nullptr, dst + (long)fl.f.C0 * outCS, act, slope, outBS, outCS, OW, 1, fl.f.R, s,
+                       false, fl.H + V - 1, V, OH);
+}
+
+int mpa_conv2d_fold_supported(const mpa_conv_desc* d) {
+  if (!d) return 0;
+  return fold_launch(d, 2).ok ? 1 : 0;
+}
+
+int mpa_conv2d_fwd_folded(const mpa_conv_desc* d, const float* x, const float* w_packed, const float* bias, float* y, int act,
+                          float slope, void* stream) {
+  if (!d || !x || !w_packed || !y || d->B <= 0) return MPA_ERR_ARG;
+  const FoldLaunch fl = fold_launch(d, 2);
+  if (!fl.ok) return MPA_ERR_UNSUPPORTED;
+  return conv_folded_impl(d, fl, x, w_packed, bias, y, act, slope, (hipStream_t)stream);
+}
+
 int mpa_conv2d_fwd(const mpa_conv_desc* d, const float* x, const float* w_packed, const float* bias, float* y,
                    int act, float slope, void* stream) {
   if (!d || !x || !w_packed || !y || d->B <= 0) return MPA_ERR_ARG;
@@ -713,6 +797,10 @@ int mpa_conv2d_fwd_stats(const mpa_conv_desc* d, const float* x, const float* w_
 int mpa_conv2d_bwd_data(const mpa_conv_desc* d, const float* dy, const float* w_packed, float* dx, void* stream) {
   if (!d || !dy || !w_packed || !dx || d->B <= 0) return MPA_ERR_ARG;
   if (plan_head(d, 1).ok) return mpa_conv_head_bwd_data(d, dy, w_packed, dx, (hipStream_t)stream);
+  {
+    const FoldLaunch fl = fold_launch(d, 1);
+    if (fl.ok) return conv_folded_impl(d, fl, dy, w_packed, nullptr, dx, MPA_ACT_NONE, 0.f, (hipStream_t)stream);
+  }
   BwdDataGeom g = bwd_data_geom(d);
   if (!g.ok) return MPA_ERR_UNSUPPORTED;
   const long inBS = (long)d->Cin * d->H * d->W, inCS = (long)d->H * d->W;
@@ -763,6 +851,17 @@ int mpa_conv2d_describe_plan(const mpa_conv_desc* d, int mode, char* buf, int bu
              w.ga ? "_g" : "", w.NBC, w.NTW, w.COT, w.coTiles, w.nPerBlock, w.nTiles, w.XCH, w.TH, w.TW, w.DP, w.tilesY,
              w.tilesX, w.S, w.quad, w.ef, w.lds_bytes);
     return MPA_OK;
+  }
+  if (mode == 1 || mode == 3) {            // 3: the forward pass with the cout remainder fold (pack mode 2)
+    const FoldLaunch fl = fold_launch(d, mode == 3 ? 2 : 1);
+    if (fl.ok) {
+      snprintf(buf, buflen, "fold %d + %dx%d rows: main fwd<%d,%d> COT=%d coTiles=%d tile=%dx%d tiles=%dx%d kwvec=%d | fold fwd<%d,%d> kh=%d stride=%d tile=%dx%d tiles=%dx%d kwvec=%d",
+               fl.f.C0, fl.f.R, fl.f.V, fl.main.NB, fl.main.PB, fl.main.COT, fl.main.coTiles, fl.main.TH, fl.main.TW, fl.main.tilesY,
+               fl.main.tilesX, fl.main.KWS, fl.fold.NB, fl.fold.PB, fl.kh + fl.f.V - 1, fl.f.V, fl.fold.TH, fl.fold.TW, fl.fold.tilesY,
+               fl.fold.tilesX, fl.fold.KWS);
+      return MPA_OK;
+    }
+    if (mode == 3) return MPA_ERR_UNSUPPORTED;
   }
   FwdPlan f;
   if (mode == 0) f = plan_fwd(d->B, d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw);

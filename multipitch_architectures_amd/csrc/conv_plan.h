@@ -218,6 +218,32 @@ inline FwdPlan plan_bwd_data(const mpa_conv_desc* d, const BwdDataGeom& g) {
                   g.xphase ? d->sw : 1);
 }
 
+// ------------------------------------------------------------------------------------------------ cout remainder fold
+// 15x15 stride-1 layers whose output channels are not a multiple of 16 (the CNN families: 70 = 64 + 6, 20 = 16 + 4,
+// 40 = 32 + 8, 100 = 96 + 4) pad the last MFMA tile: 70 couts run as 80.  Forward and backward-data (whose derived conv
+// has Cout' = Cin) then take two launches into the same tensor: channels [0, C0) as an ordinary convolution and the R
+// remaining channels as V * R rows of one 16-row tile -- V vertically adjacent output rows per channel, a (kh + V - 1)-row
+// filter that is the original shifted down by v rows, vertical stride V (the mapping bwd_data_yphase uses for the 6-channel
+// input layer).  12 of 16 rows busy for 16/15 of the taps instead of 6 of 16.  The backward-weight has its own tap fold
+// (conv_wgrad15.hip).
+struct FoldPlan {
+  bool ok;
+  int C0, R, V;      // main channels, remainder channels, output rows per remainder channel and launch row
+};
+
+inline FoldPlan plan_fold(int Cout_out, int kh, int kw, int sh, int sw, int H) {
+  FoldPlan f{};
+  f.ok = false;
+  if (kh != 15 || kw != 15 || sh != 1 || sw != 1 || getenv("MPA_FOLD_OFF")) return f;
+  f.R = Cout_out % 16;
+  f.C0 = Cout_out - f.R;
+  if (f.R < 1 || f.R > 8 || f.C0 < 16) return f;
+  f.V = f.R <= 4 ? 4 : 2;
+  if (H < f.V) return f;
+  f.ok = true;
+  return f;
+}
+
 // ------------------------------------------------------------------------------------------------ backward-weight
 constexpr int WGG_DEPTH = 2;      // conv_wgrad_g_kernel: 16-pixel groups whose dY quads are in flight
 constexpr int WGG_SLACK = 64;      // ... and zeroed LDS words behind its X tile

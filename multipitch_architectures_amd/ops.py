@@ -364,6 +364,12 @@ class Conv2dFn(torch.autograd.Function):
                 return y, partials
             return y
         ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
+        if not with_stats and _lib().mpa_conv2d_fold_supported(ctypes.byref(d)):
+            # 15x15 layer with a cout remainder (70 = 64 + 6): two launches, the remainder as row pairs of one MFMA tile
+            wp = _packed(weight, d, 2)
+            _chk(_probed("fwd", d, lambda: _lib().mpa_conv2d_fwd_folded(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(y), act,
+                                                                        float(slope), _s())), "mpa_conv2d_fwd_folded")
+            return y
         wp = _packed(weight, d, 0)
         if with_stats:
             if act != ACT_NONE:

@@ -742,3 +742,54 @@ def test_poolrows_dropout_add_nan_propagates_and_eval_mode(dev, kh):
         ops.poolrows_dropout_add(h.to(dev), _rand((1, 2, 19, 4), 6).to(dev), kh, 0.2, True)
     with pytest.raises(RuntimeError):
         ops.poolrows_dropout_add(h.to(dev), None, 5, 0.2, True)
+
+
+# ---------------------------------------------------------------------------------------------- cout remainder fold
+# 15x15 stride-1 layers whose output channels are not a multiple of 16 (the CNN families, basic_cnns.py:371-387): forward
+# and backward-data as two launches -- channels [0, C0) + the remainder as V * R rows of one MFMA tile (conv_plan.h:
+# plan_fold).  (B, Cin, H, W, Cout, forward folded?, backward-data folded?)
+FOLD_CASES = [(2, 70, 20, 40, 70, True, True),      # DRCNN:L channels: 64 + 6 rows x 2
+              (2, 20, 30, 40, 20, True, True),      # CNN:XS: 16 + 4 rows x 4
+              (1, 40, 33, 50, 40, True, True),      # 32 + 8 x 2, odd height
+              (2, 6, 75, 216, 70, True, False),     # first layer of DRCNN:L: backward-data keeps its 6-channel row phases
+              (1, 70, 9, 16, 100, True, True),      # 96 + 4 x 4 forward, 64 + 6 x 2 backward-data, height 9
+              (3, 33, 7, 12, 17, True, True),       # a single remainder channel
+              (2, 64, 20, 40, 64, False, False)]    # multiples of 16: nothing to fold
+
+
+@pytest.mark.parametrize("case", FOLD_CASES, ids=lambda c: "x".join(map(str, c[:5])))
+def test_conv15_cout_remainder_fold(dev, case):
+    import ctypes
+    from multipitch_architectures_amd import _lib as L, ops
+    B, Cin, H, W, Cout, fwd_fold, bwd_fold = case
+    d = L.ConvDesc(B, Cin, H, W, Cout, 15, 15, 1, 1, 7, 7)
+    lib = L.load()
+    buf = ctypes.create_string_buffer(1024)
+    assert bool(lib.mpa_conv2d_fold_supported(ctypes.byref(d))) == fwd_fold
+    assert (lib.mpa_conv2d_describe_plan(ctypes.byref(d), 3, buf, 1024) == 0) == fwd_fold
+    assert lib.mpa_conv2d_describe_plan(ctypes.byref(d), 1, buf, 1024) == 0
+    assert buf.value.decode().startswith("fold ") == bwd_fold, buf.value
+    x = _rand((B, Cin, H, W), 1)
+    w = _rand((Cout, Cin, 15, 15), 2, (2.0 / (Cin * 225)) ** 0.5)
+    b = _rand((Cout,), 3, 0.1)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    zr = F.conv2d(xr, wr, br, padding=7)
+    yr = F.leaky_relu(zr, 0.3)
+    gy = _rand(tuple(yr.shape), 4) * (zr.detach().abs() > 1e-4).float()
+    yr.backward(gy.double())
+    xg, wg, bg = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    y = ops.conv2d(xg, wg, bg, (1, 1), (7, 7), ops.ACT_LRELU, 0.3)
+    y.backward(gy.to(dev))
+    _close(y, yr, 2e-5, "y")
+    _close(xg.grad, xr.grad, 2e-5, "dx")
+    _close(wg.grad, wr.grad, 5e-5, "dw")
+    _close(bg.grad, br.grad, 5e-5, "db")
+
+
+def test_conv15_fold_switch(dev, monkeypatch):
+    import ctypes
+    from multipitch_architectures_amd import _lib as L
+    d = L.ConvDesc(2, 70, 20, 40, 70, 15, 15, 1, 1, 7, 7)
+    assert L.load().mpa_conv2d_fold_supported(ctypes.byref(d)) == 1
+    monkeypatch.setenv("MPA_FOLD_OFF", "1")
+    assert L.load().mpa_conv2d_fold_supported(ctypes.byref(d)) == 0
