@@ -855,10 +855,10 @@ int mpa_conv2d_describe_plan(const mpa_conv_desc* d, int mode, char* buf, int bu
   if (mode == 1 || mode == 3) {            // 3: the forward pass with the cout remainder fold (pack mode 2)
     const FoldLaunch fl = fold_launch(d, mode == 3 ? 2 : 1);
     if (fl.ok) {
-      snprintf(buf, buflen, "fold %d + %dx%d rows: main fwd<%d,%d> COT=%d coTiles=%d tile=%dx%d tiles=%dx%d kwvec=%d | fold fwd<%d,%d> kh=%d stride=%d tile=%dx%d tiles=%dx%d kwvec=%d",
+      snprintf(buf, buflen, "fold %d + %dx%d rows: main fwd<%d,%d> COT=%d coTiles=%d tile=%dx%d tiles=%dx%d kwvec=%d | fold fwd<%d,%d> kh=%d stride=%d tile=%dx%d tiles=%dx%d kwvec=%d lds=%zuB",
                fl.f.C0, fl.f.R, fl.f.V, fl.main.NB, fl.main.PB, fl.main.COT, fl.main.coTiles, fl.main.TH, fl.main.TW, fl.main.tilesY,
                fl.main.tilesX, fl.main.KWS, fl.fold.NB, fl.fold.PB, fl.kh + fl.f.V - 1, fl.f.V, fl.fold.TH, fl.fold.TW, fl.fold.tilesY,
-               fl.fold.tilesX, fl.fold.KWS);
+               fl.fold.tilesX, fl.fold.KWS, std::max(fl.main.lds_bytes, fl.fold.lds_bytes));
       return MPA_OK;
     }
     if (mode == 3) return MPA_ERR_UNSUPPORTED;

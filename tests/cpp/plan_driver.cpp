@@ -15,6 +15,20 @@ static void one(const char* name, int B, int Cin, int H, int W, int Cout, int kh
   } else {
     printf("%s dgrad ok=0\n", name);
   }
+  for (int mode = 0; mode < 2; ++mode) {          // head conv2 kernels (conv_head.hip)
+    const HeadPlan h = plan_head(&d, mode);
+    if (h.ok) printf("%s head%d ok=1 MT=%d WM=%d WN=%d CK=%d chunks=%d NT=%d rows=%d PXT=%d tilesP=%d XS=%d P=%d lds=%zu\n", name, mode,
+                     h.MT, h.WM, h.WN, h.CK, h.nChunks, h.NT, h.Mrows, h.PXT, h.tilesP, h.XS, h.P, h.lds_bytes);
+  }
+  {
+    const HeadWgPlan h = plan_head_wgrad(&d);
+    if (h.ok) printf("%s headwg ok=1 MT=%d coGroups=%d chGroups=%d S=%d NCS=%d SEG=%d NRB=%d RB=%d itemsPer=%ld XUs=%d DUs=%d lds=%zu\n",
+                     name, h.MT, h.coGroups, h.chGroups, h.S, h.NCS, h.SEG, h.NRB, h.RB, h.itemsPer, h.XUs, h.DUs, h.lds_bytes);
+    const FoldPlan f = plan_fold(Cout, kh, kw, sh, sw, H);
+    if (f.ok) printf("%s foldf ok=1 C0=%d R=%d V=%d lds=0\n", name, f.C0, f.R, f.V);
+    const FoldPlan fb = plan_fold(Cin, kh, kw, sh, sw, H);
+    if (fb.ok) printf("%s foldb ok=1 C0=%d R=%d V=%d lds=0\n", name, fb.C0, fb.R, fb.V);
+  }
   const Wg15Plan q = plan_wgrad15(&d);
   if (q.ok) printf("%s wgrad15 ok=1 ga=%d n32=%d has16=%d fold=%d S=%d TH=%d tilesY=%d lds=%zu\n", name, q.ga, q.n32, q.has16, q.fold_R,
                    q.S, q.TH, q.tilesY, q.lds_bytes);
@@ -35,6 +49,7 @@ int main() {
   one("down4a", 256, 128, 4, 13, 128, 3, 3, 1, 1, 1, 1);
   one("conv2_80", 256, 128, 75, 216, 80, 3, 3, 1, 3, 1, 0);
   one("conv2_200", 256, 128, 75, 216, 200, 3, 3, 1, 3, 1, 0);
+  one("conv2_80_b32", 32, 128, 75, 216, 80, 3, 3, 1, 3, 1, 0);
   one("strided_unsupported", 4, 8, 20, 20, 8, 3, 3, 2, 2, 1, 1);
   return 0;
 }

@@ -52,4 +52,23 @@ def test_the_choices_design_md_quotes(plans):
     assert w["ga"] == 1 and w["n32"] == 4 and w["fold"] == 0
     p = plans[("prefilt", "wgrad15")]
     assert (p["n32"], p["has16"], p["fold"]) == (2, 0, 6)               # 70 couts = 2 x 32 + tap-folded 6
-    assert plans[("conv2_80", "wgrad")]["NBC"] == 5                     # head conv2: 80-cout block shape
+    assert plans[("conv2_80", "wgrad")]["NBC"] == 5                     # head conv2 on the generic kernels: 80-cout block shape
+
+
+def test_head_conv2_and_fold_plans(plans):
+    """csrc/conv_head.hip (the head's 3x3 stride-(1,3) conv2) and the cout remainder fold of the 15x15 layers"""
+    f, b, w = plans[("conv2_80", "head0")], plans[("conv2_80", "head1")], plans[("conv2_80", "headwg")]
+    assert (f["MT"], f["WM"], f["WN"], f["NT"], f["CK"]) == (5, 1, 4, 9, 4)      # 5 cout tiles x 5 pixel blocks per wave, 2 WGs / CU
+    assert f["PXT"] * f["tilesP"] >= f["P"] and f["XS"] % 32 == 16 and f["lds"] <= 78 * 1024
+    assert (b["MT"], b["WM"], b["WN"], b["NT"], b["rows"]) == (6, 4, 2, 3, 384)  # rows = (channel, column phase) pairs
+    assert b["XS"] % 32 == 16
+    assert (w["MT"], w["coGroups"], w["chGroups"], w["NCS"], w["SEG"], w["NRB"]) == (5, 1, 2, 2, 36, 1)
+    assert w["S"] * w["chGroups"] * w["coGroups"] == 256                         # one workgroup per CU
+    f2, w2 = plans[("conv2_200", "head0")], plans[("conv2_200", "headwg")]
+    assert (f2["MT"], f2["WM"]) == (7, 2) and (w2["MT"], w2["coGroups"]) == (5, 3)
+    assert ("conv2_80_b32", "head0") not in plans                                # small launch: the generic forward kernel
+    assert plans[("conv2_80_b32", "headwg")]["NRB"] == 2                         # row blocks give 128 slices their items
+    for k in ("foldf", "foldb"):
+        p = plans[("prefilt", k)]
+        assert (p["C0"], p["R"], p["V"]) == (64, 6, 2)                           # 70 = 64 + 6 rows x 2
+    assert ("upconv4b", "foldf") not in plans and ("conv2_80", "foldf") not in plans
