@@ -292,14 +292,14 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const HeadWgParams p) {
     const int u = (wave + 4 * n) * 64 + lane;
     const int c = (int)(((unsigned)u * (unsigned)p.xmagic) >> 20), o = u - c * p.XPu;
     const int ch = cg * 64 + c;
-    xpo[n] = (n < nx && c < 64 && o < p.XPu - 1 && ch < p.Cin) ? ch * p.HW + 4 * o : -1;
+    xpo[n] = (n < nx && c < 64 && o < 3 * p.KS && ch < p.Cin) ? ch * p.HW + 4 * o : -1;      // 3 KS units per row segment
   }
 #pragma unroll
   for (int n = 0; n < HEAD_WG_ND; ++n) {
     const int u = (wave + 4 * n) * 64 + lane;
     const int row = (int)(((unsigned)u * (unsigned)p.dmagic) >> 20), o = u - row * p.DPu;
     const int co = cog * MT * 16 + row;
-    dpo[n] = (n < nd && row < 16 * MT && o < p.DPu - 1 && co < p.Cout) ? co * p.P + 4 * o : -1;
+    dpo[n] = (n < nd && row < 16 * MT && o < p.KS && co < p.Cout) ? co * p.P + 4 * o : -1;
   }
 
   for (long item = it_first; item < it_last; ++item) {

@@ -662,8 +662,11 @@ inline HeadWgPlan plan_head_wgrad(const mpa_conv_desc* d) {
   for (pl.NCS = 1; pl.NCS <= OW / 4; ++pl.NCS) {
     if (OW % (4 * pl.NCS)) continue;
     pl.SEG = OW / pl.NCS;
-    pl.XPu = 3 * pl.SEG / 4 + 1;
-    pl.DPu = pl.SEG / 4 + 1;
+    // LDS pitches in 16-byte units, odd: lane j of an operand read sits at j * pitch words, and with pitch / 4 odd the 16
+    // lanes spread over 8 bank groups (2-way); an even unit count folds them onto 2 or 4 (measured with the first version,
+    // pitch 28 units: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.82)
+    pl.XPu = (3 * pl.SEG / 4 + 1) | 1;
+    pl.DPu = (pl.SEG / 4 + 1) | 1;
     pl.XUs = (int)(mpa_cdiv(64L * pl.XPu, 64) * 64);
     pl.DUs = (int)(mpa_cdiv(16L * pl.MT * pl.DPu, 64) * 64);
     pl.lds_bytes = (size_t)(3 * pl.XUs + 2 * pl.DUs) * 16;
