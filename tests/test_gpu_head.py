@@ -53,6 +53,8 @@ CASES = [
     ((1, 40, 174, 216, 100), ("head_gemm<7,1,4>", "head_gemm<4,2,4>", "head_wgrad<4>")),      # T = 174
     ((2, 64, 75, 216, 30), ("fwd<", "head_gemm<6,2,4>", "head_wgrad<2>")),                    # 2 cout tiles: generic forward
     ((5, 128, 5, 12, 64), ("head_gemm<4,1,4>", "head_gemm<6,4,2>", "head_wgrad<4>")),         # smallest width
+    ((1, 144, 10, 24, 120), ("head_gemm<4,2,4>", "head_gemm<7,4,2>", "head_wgrad<4>")),       # 8 cout tiles over 2 wave rows; 27 (channel, phase) tiles; 3 channel groups
+    ((2, 32, 1, 24, 64), ("head_gemm<4,1,4>", "fwd<", "head_wgrad<4>")),                      # one image row: every halo row is a zero page
 ]
 
 
