@@ -779,6 +779,7 @@ int mpa_conv2d_fwd(const mpa_conv_desc* d, const float* x, const float* w_packed
 
 int64_t mpa_conv2d_fwd_stats_rows(const mpa_conv_desc* d) {
   if (!d) return MPA_ERR_ARG;
+  if (plan_head(d, 0).ok) return MPA_ERR_UNSUPPORTED;
   FwdPlan pl = plan_fwd(d->B, d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw);
   if (!pl.ok) return MPA_ERR_UNSUPPORTED;
   return (int64_t)d->B * pl.tilesY * pl.tilesX;
@@ -789,6 +790,7 @@ int mpa_conv2d_fwd_stats(const mpa_conv_desc* d, const float* x, const float* w_
   if (!d || !x || !w_packed || !y || !partials || d->B <= 0) return MPA_ERR_ARG;
   const int OH = (d->H + 2 * d->ph - d->kh) / d->sh + 1, OW = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
   if (OH <= 0 || OW <= 0) return MPA_ERR_ARG;
+  if (plan_head(d, 0).ok) return MPA_ERR_UNSUPPORTED;      // mode-0 banks of that geometry are in conv_head.hip's layout
   return conv_fwd_impl(d->B, d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw, x, w_packed, bias,
                        y, MPA_ACT_NONE, 0.f, (long)d->Cout * OH * OW, (long)OH * OW, OW, 1, d->Cout, (hipStream_t)stream,
                        false, 0, 1, 0, partials);

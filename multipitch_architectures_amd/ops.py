@@ -331,6 +331,9 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, act, slope, with_stats=False):
+        # no zero tensor for the gradient of the non-differentiable `partials` output: autograd would otherwise fill one per
+        # BatchNorm layer and step (18 fill launches for SAUnet:L)
+        ctx.set_materialize_grads(False)
         x, weight, bias = _c(x, "conv input"), _c(weight, "conv weight"), _c(bias, "conv bias")
         B, Cin, H, W = x.shape
         Cout, Cin_w, kh, kw = weight.shape
@@ -388,6 +391,8 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dpartials=None):
+        if dy is None:                     # (set_materialize_grads(False): nothing flowed into y)
+            return None, None, None, None, None, None, None, None
         x, weight, y = ctx.saved_tensors
         d, lib = ctx.desc, _lib()
         dy = _c(dy, "conv grad")
