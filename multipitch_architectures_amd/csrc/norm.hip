@@ -479,8 +479,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ save_mean,
                                                            const float* __restrict__ save_invstd,
                                                            const double* __restrict__ stats, float* __restrict__ dx, int C,
-                                                           int HW, double count, int relu, int train) {
+                                                           int HW, double count, int relu, int train,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const int plane = blockIdx.x, c = plane % C;
+  // the parameter gradients are the two sums themselves: written here by the first image's blocks instead of by an 18th-of-a-
+  // step launch of their own (dgamma != nullptr)
+  if (dgamma != nullptr && plane < C && blockIdx.y == 0 && threadIdx.x == 0) {
+    dbeta[c] = (float)stats[2 * c];
+    dgamma[c] = (float)stats[2 * c + 1];
+  }
   const float mu = save_mean[c], is = save_invstd[c];
   const float k = gamma[c] * is;
   const bool from_x = beta != nullptr;              // ReLU mask recomputed from x (see bn_bwd_stats_kernel)
@@ -677,9 +684,7 @@ int mpa_bn_relu_bwd(const float* dy, const float* x, const float* y, const float
                   stats_ws, B, C, HW, relu);
   const int chunks = (int)std::max<long>(1, std::min<long>(mpa_cdiv(HW, 1024), 64));
   MPA_LAUNCH(bn_bwd_apply_kernel, dim3(B * C, chunks), dim3(256), 0, s, dy, x, y, gamma, beta, save_mean, save_invstd,
-                     (const double*)stats_ws, dx, C, HW, (double)B * HW, relu, train);
-  MPA_LAUNCH(bn_bwd_finalize_kernel, dim3((unsigned)mpa_cdiv(C, 64)), dim3(64), 0, s, (const double*)stats_ws, dgamma,
-                     dbeta, C);
+                     (const double*)stats_ws, dx, C, HW, (double)B * HW, relu, train, dgamma, dbeta);
   return mpa_launch_status();
 }
 
@@ -736,7 +741,7 @@ int mpa_bn_relu_bwd_apply(const float* dy, const float* x, const float* gamma, c
   hipStream_t s = (hipStream_t)stream;
   const int chunks = (int)std::max<long>(1, std::min<long>(mpa_cdiv(HW, 1024), 64));
   MPA_LAUNCH(bn_bwd_apply_kernel, dim3(B * C, chunks), dim3(256), 0, s, dy, x, x, gamma, beta, save_mean, save_invstd, stats,
-             dx, C, HW, count, relu, 1);
+             dx, C, HW, count, relu, 1, (float*)nullptr, (float*)nullptr);
   return mpa_launch_status();
 }
 
