@@ -5,6 +5,8 @@
 // The LDS image of each operand is laid out along whichever global dimension is contiguous so that both the
 // global loads and the LDS stores stay coalesced / conflict-free; MFMA fragment reads use runtime strides.
 #include "mpa_common.h"
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 
 namespace {
@@ -306,6 +308,12 @@ int gemm_impl(GemmParams p, int nbatch, int shared_c, hipStream_t s) {
       const double rounds = (double)mpa_cdiv(blocks * sp * nbatch, 512);
       const double cost = rounds * ((double)mpa_cdiv(K, sp) + 96.0) * TM[v] * TN[v] / EFF[v] * (sp > 1 ? 1.03 : 1.0);
       if (cost < best) { best = cost; variant = v; splits = sp; }
+    }
+  }
+  if (const char* e = getenv("MPA_GEMM_FORCE")) {            // diagnostics: "variant,splits"
+    int fv = -1, fs = 0;
+    if (sscanf(e, "%d,%d", &fv, &fs) == 2 && fv >= 0 && fv < 4 && fs >= 1 && fs <= 32 && (fs == 1 || act == MPA_ACT_NONE)) {
+      variant = fv; splits = fs;
     }
   }
   if (splits > 1) {
