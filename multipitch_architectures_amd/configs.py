@@ -98,4 +98,5 @@ VARIANT_CONFIGS = {
     "simple_u_net_polyphony_classif": dict(_VT, num_polyphony_steps=24),
     "simple_u_net_doubleselfattn_polyphony": dict(_VT, **_VA),
     "simple_u_net_doubleselfattn_polyphony_classif": dict(_VT, **_VA, num_polyphony_steps=24),
+    "basic_cnn_pool": dict(n_chan_layers=[8, 6, 5, 4], n_bins_out=72),
 }

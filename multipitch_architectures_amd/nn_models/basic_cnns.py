@@ -91,3 +91,44 @@ class deep_cnn_segm_sigmoid(nn.Module):
         conv3_lrelu = self.conv3(conv2_lrelu)
         y_pred = self.conv4(conv3_lrelu)
         return y_pred
+
+
+class basic_cnn_pool(nn.Module):
+    """basic_cnns.py:68-130 -- the "pool" variant of Zeitler's basic CNN: long max-poolings instead of strided convolutions
+    (conv1 15x15 + pool (8,1); conv2 3x3 "same" + pool (3,3); conv3 (3,1); conv4 as everywhere).  HCQT (B,6,75,216) ->
+    (B,1,1,n_bins_out).  No experiment script uses it; built from the same blocks as the classes above."""
+
+    def __init__(self, n_chan_input=6, n_chan_layers=[20, 20, 10, 1], n_bins_in=216, n_bins_out=12, a_lrelu=0.3,
+                 p_dropout=0.2):
+        super().__init__()
+        n_in, n_ch = n_chan_input, n_chan_layers
+        last_kernel_size = n_bins_in // 3 + 1 - n_bins_out
+        self.layernorm = LayerNorm(normalized_shape=[n_in, n_bins_in])
+        self.conv1 = ConvActPoolDrop(
+            Conv2d(n_in, n_ch[0], kernel_size=(15, 15), padding=(7, 7), stride=(1, 1)),
+            LeakyReLU(negative_slope=a_lrelu),
+            MaxPool2d(kernel_size=(8, 1), stride=(8, 1), padding=(0, 0)),
+            Dropout(p=p_dropout))
+        self.conv2 = ConvActPoolDrop(
+            Conv2d(n_ch[0], n_ch[1], kernel_size=(3, 3), padding=(1, 1), stride=(1, 1)),
+            LeakyReLU(negative_slope=a_lrelu),
+            MaxPool2d(kernel_size=(3, 3), stride=(3, 3), padding=(0, 0)),
+            Dropout(p=p_dropout))
+        self.conv3 = ConvActPoolDrop(
+            Conv2d(n_ch[1], n_ch[2], kernel_size=(3, 1), padding=(0, 0), stride=(1, 1)),
+            LeakyReLU(negative_slope=a_lrelu),
+            Dropout(p=p_dropout))
+        self.conv4 = OutputHead(
+            Conv2d(n_ch[2], n_ch[3], kernel_size=(1, 1), padding=(0, 0), stride=(1, 1)),
+            LeakyReLU(negative_slope=a_lrelu),
+            Dropout(p=p_dropout),
+            Conv2d(n_ch[3], 1, kernel_size=(1, last_kernel_size), padding=(0, 0), stride=(1, 1)),
+            Sigmoid())
+
+    def forward(self, x):
+        x_norm = self.layernorm.forward_cf(x)
+        conv1_lrelu = self.conv1(x_norm)
+        conv2_lrelu = self.conv2(conv1_lrelu)
+        conv3_lrelu = self.conv3(conv2_lrelu)
+        y_pred = self.conv4(conv3_lrelu)
+        return y_pred

@@ -1,4 +1,4 @@
-"""The 8 U-Net variants the reference exports but no experiment script uses (re-compositions of the hot-path blocks,
+"""The 8 U-Net variants (and basic_cnn_pool) the reference exports but no experiment script uses (re-compositions of the hot-path blocks,
 nn_models/unet_cnns.py bottom): HIP classes against tests/golden/xcls-*.npz, produced by the reference classes themselves
 (oracle/make_goldens_variants.py) -- evaluation outputs <= 1e-4, one train-mode step: loss and every parameter gradient."""
 import glob
