@@ -491,7 +491,7 @@ struct PackParams {
   // head conv2 (conv_head.hip): packed[chunk][(kq * hNT + tap) * hMTT + mtile][lane 64], hAUw words per chunk;
   // lane (i, kk) of m-tile mt holds A[16 mt + i][chunk * CK + 4 kq + kk][tap].  head 1: forward (row = cout, tap = 3 dy + dx),
   // head 2: backward-data (row = 3 cin + dx, contraction channel = cout, tap = dy)
-  int head, hNT, hMTT, hCK;
+  int head, hNT, hMTT, hCK, hNG;     // head 3 / 4: tall (kh,1) filters forward / backward-data, hNG tap groups of hNT (plan_tall)
   long hAUw;
 };
 
@@ -506,7 +506,16 @@ __device__ __forceinline__ void conv_pack_head_range(const PackParams& p, long f
       const int mt = (int)(r % p.hMTT); r /= p.hMTT;
       const int tap = (int)(r % p.hNT);
       const int kq = (int)(r / p.hNT);
-      const int m = 16 * mt + (lane & 15), k = (int)chunk * p.hCK + 4 * kq + (lane >> 4);
+      const int m = 16 * mt + (lane & 15);
+      if (p.head >= 3) {               // chunk = (channel chunk, tap group); one column of kh taps
+        const int cq = (int)(chunk / p.hNG), tg = (int)(chunk - (long)cq * p.hNG);
+        const int k = cq * p.hCK + 4 * kq + (lane >> 4), dy = tg * p.hNT + tap;
+        if (p.head == 3) { if (m < p.Cout_w && k < p.Cin_w) v = p.w[((long)m * p.Cin_w + k) * p.kh_w + dy]; }
+        else if (m < p.Cin_w && k < p.Cout_w) v = p.w[((long)k * p.Cin_w + m) * p.kh_w + dy];
+        p.wp[i] = v;
+        continue;
+      }
+      const int k = (int)chunk * p.hCK + 4 * kq + (lane >> 4);
       if (p.head == 1) {
         if (m < p.Cout_w && k < p.Cin_w) v = p.w[((long)m * p.Cin_w + k) * 9 + tap];
       } else {
@@ -670,8 +679,17 @@ static int pack_params(const mpa_conv_desc* d, int mode, const float* w, float* 
   if (mode == 0 || mode == 1) {
     const HeadPlan hp = plan_head(d, mode);
     if (hp.ok) {
-      p.head = mode + 1; p.hNT = hp.NT; p.hMTT = hp.MTT; p.hAUw = hp.AUw; p.hCK = hp.CK;
+      p.head = mode + 1; p.hNT = hp.NT; p.hMTT = hp.MTT; p.hAUw = hp.AUw; p.hCK = hp.CK; p.hNG = 1;
       p.total = (long)hp.nChunks * hp.AUw;
+      return MPA_OK;
+    }
+  }
+  if (mode == 0 || mode == 1) {
+    int NG = 1;
+    const HeadPlan tp = plan_tall(d, mode + 2, &NG);
+    if (tp.ok) {
+      p.head = mode + 3; p.hNT = tp.NT; p.hMTT = tp.MTT; p.hAUw = tp.AUw; p.hCK = tp.CK; p.hNG = NG;
+      p.total = (long)tp.nChunks * tp.AUw;
       return MPA_OK;
     }
   }
@@ -773,13 +791,14 @@ int mpa_conv2d_fwd(const mpa_conv_desc* d, const float* x, const float* w_packed
   const int OH = (d->H + 2 * d->ph - d->kh) / d->sh + 1, OW = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
   if (OH <= 0 || OW <= 0) return MPA_ERR_ARG;
   if (plan_head(d, 0).ok) return mpa_conv_head_fwd(d, x, w_packed, bias, y, act, slope, (hipStream_t)stream);
+  if (plan_tall(d, 2).ok) return mpa_conv_tall_fwd(d, x, w_packed, bias, y, act, slope, (hipStream_t)stream);
   return conv_fwd_impl(d->B, d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw, x, w_packed, bias,
                        y, act, slope, (long)d->Cout * OH * OW, (long)OH * OW, OW, 1, d->Cout, (hipStream_t)stream);
 }
 
 int64_t mpa_conv2d_fwd_stats_rows(const mpa_conv_desc* d) {
   if (!d) return MPA_ERR_ARG;
-  if (plan_head(d, 0).ok) return MPA_ERR_UNSUPPORTED;
+  if (plan_head(d, 0).ok || plan_tall(d, 2).ok) return MPA_ERR_UNSUPPORTED;
   FwdPlan pl = plan_fwd(d->B, d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw);
   if (!pl.ok) return MPA_ERR_UNSUPPORTED;
   return (int64_t)d->B * pl.tilesY * pl.tilesX;
@@ -790,7 +809,7 @@ int mpa_conv2d_fwd_stats(const mpa_conv_desc* d, const float* x, const float* w_
   if (!d || !x || !w_packed || !y || !partials || d->B <= 0) return MPA_ERR_ARG;
   const int OH = (d->H + 2 * d->ph - d->kh) / d->sh + 1, OW = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
   if (OH <= 0 || OW <= 0) return MPA_ERR_ARG;
-  if (plan_head(d, 0).ok) return MPA_ERR_UNSUPPORTED;      // mode-0 banks of that geometry are in conv_head.hip's layout
+  if (plan_head(d, 0).ok || plan_tall(d, 2).ok) return MPA_ERR_UNSUPPORTED;      // mode-0 banks of that geometry are in conv_head.hip's layout
   return conv_fwd_impl(d->B, d->Cin, d->H, d->W, d->Cout, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw, x, w_packed, bias,
                        y, MPA_ACT_NONE, 0.f, (long)d->Cout * OH * OW, (long)OH * OW, OW, 1, d->Cout, (hipStream_t)stream,
                        false, 0, 1, 0, partials);
@@ -799,6 +818,7 @@ int mpa_conv2d_fwd_stats(const mpa_conv_desc* d, const float* x, const float* w_
 int mpa_conv2d_bwd_data(const mpa_conv_desc* d, const float* dy, const float* w_packed, float* dx, void* stream) {
   if (!d || !dy || !w_packed || !dx || d->B <= 0) return MPA_ERR_ARG;
   if (plan_head(d, 1).ok) return mpa_conv_head_bwd_data(d, dy, w_packed, dx, (hipStream_t)stream);
+  if (plan_tall(d, 3).ok) return mpa_conv_tall_bwd_data(d, dy, w_packed, dx, (hipStream_t)stream);
   {
     const FoldLaunch fl = fold_launch(d, 1);
     if (fl.ok) return conv_folded_impl(d, fl, dy, w_packed, nullptr, dx, MPA_ACT_NONE, 0.f, (hipStream_t)stream);
@@ -823,6 +843,15 @@ int mpa_conv2d_bwd_data(const mpa_conv_desc* d, const float* dy, const float* w_
 
 int mpa_conv2d_describe_plan(const mpa_conv_desc* d, int mode, char* buf, int buflen) {
   if (!d || !buf || buflen <= 0) return MPA_ERR_ARG;
+  if (mode == 0 || mode == 1) {
+    int NG = 1;
+    const HeadPlan tp = plan_tall(d, mode + 2, &NG);
+    if (tp.ok) {
+      snprintf(buf, buflen, "tall_gemm<%d,%d,%d> rows=%d tiles=%d K=%d taps=%dx%d chunks=%d px/wg=%d tiles/img=%d XS=%d lds=%zuB", tp.MT,
+               tp.WM, tp.WN, tp.Mrows, tp.MTT, tp.K, NG, tp.NT, tp.nChunks, tp.PXT, tp.tilesP, tp.XS, tp.lds_bytes);
+      return MPA_OK;
+    }
+  }
   if (mode == 0 || mode == 1) {
     const HeadPlan hp = plan_head(d, mode);
     if (hp.ok) {

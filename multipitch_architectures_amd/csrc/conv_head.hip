@@ -36,9 +36,11 @@ struct HeadParams {
   const float* bias;
   float* out;
   int K, Mrows, MTT, P, SL, HALO, XS, CK, nChunks, tilesP, xinstr, xmagic;
+  int NG, grp_shift;     // tap groups per channel chunk (tall filters: chunk = (channel chunk, tap group)); slab origin shift per group
+  int used;              // words of a slab row that come from the plane
   int xslab;             // words of one X slab buffer (multiple of 256)
   int AUw;
-  int tapoff[9];
+  int tapoff[25];
   long srcBS, outBS;     // batch strides (words)
   long outPS;            // backward-data: words of one dx plane (H*W)
   int act;
@@ -47,10 +49,15 @@ struct HeadParams {
 };
 
 
-template <int MT, int WM, int WN, int NT, bool FWD>
+// MODE 0: conv2 forward (source stride 3 per pixel, rows = couts); 1: conv2 backward-data (rows = (channel, column phase), phase
+// stores); 2: tall (kh, 1) filters -- conv3 at T > 75, forward and backward-data (conv_plan.h: plan_tall): rows = output
+// channels, the kh taps in groups of NT, a chunk = (channel chunk, tap group) whose slab is the group's window of the plane
+template <int MT, int WM, int WN, int NT, int MODE>
 __global__ __launch_bounds__(WM * WN * 64) void head_gemm_kernel(const HeadParams p) {
   extern __shared__ __attribute__((aligned(16))) float hlds[];
-  constexpr int NB = 5, NW = WM * WN, PXT = WN * NB * 16, SN = FWD ? 3 : 1;
+  constexpr bool FWD = MODE != 1;
+  constexpr int NB = 5, NW = WM * WN, PXT = WN * NB * 16, SN = MODE == 0 ? 3 : 1;
+  constexpr int NSO = 12;      // X staging pieces per wave whose pattern is tabulated
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int j = lane & 15, g = lane >> 4;
@@ -61,32 +68,29 @@ __global__ __launch_bounds__(WM * WN * 64) void head_gemm_kernel(const HeadParam
 
   const float* srcb = p.src + (long)b * p.srcBS;
   const uint4* zsrc = head_zero + lane;
-  // Staging goes out one 64-lane DMA instruction ("piece") at a time, in the shadow of the MFMAs of the chunk before (issued
-  // as one burst it costs the single wave of a SIMD the MFMA slots of ~10 % of a chunk).  Unit u (16 bytes) of a chunk's
-  // slab -> channel c = u / (XS/4) (multiply-shift, checked on the host) and word o of that channel's slab row; what piece
-  // n of this wave moves is the same for every chunk: so[n] = c * SL + q (q: word of the plane), -1 = zeros (rows above /
-  // below the plane, pitch padding).  Step (kq, tap) issues X piece kq * NT + tap and filter piece kq * NT + tap.
+  // Staging: one 64-lane DMA instruction ("piece") per 1 KiB.  Unit u (16 bytes) of a chunk's slab -> channel c = u / (XS/4)
+  // (multiply-shift, checked on the host) and word o of that channel's slab row; what piece n of this wave moves is the same
+  // for every chunk (tabulated in so[]), the window of the plane it comes from depends on the chunk's tap group.
   // (measured: issuing the pieces one per tap step inside the MFMA stream was slower than the burst after the barrier --
   // the extra live addresses cost registers and the per-step branches issue slots: 106.7 against 111.8 TFLOP/s)
   constexpr bool INTER = false;
-  int so[2][NT];
-  {
-    const int xu4 = p.XS >> 2, used = SN * PXT + 2 * p.HALO, q0 = SN * p0 - p.HALO;
+  // so[n] = (channel of the chunk << 16) | word of the slab row, -1 = pitch padding / nothing to move
+  int so[NSO];
+  const int xu4 = p.XS >> 2;
 #pragma unroll
-    for (int n = 0; n < 2 * NT; ++n) {
-      const int i = wave + n * NW, u = i * 64 + lane;
-      const int c = (int)(((unsigned)u * (unsigned)p.xmagic) >> 20), o = (u - c * xu4) * 4;
-      const int q = q0 + o;
-      so[n / NT][n % NT] = (i < p.xinstr && c < p.CK && o < used && q >= 0 && q < p.SL) ? c * p.SL + q : -1;
-    }
+  for (int n = 0; n < NSO; ++n) {
+    const int i = wave + n * NW, u = i * 64 + lane;
+    const int c = (int)(((unsigned)u * (unsigned)p.xmagic) >> 20), o = (u - c * xu4) * 4;
+    so[n] = (i < p.xinstr && c < p.CK && o < p.used) ? (c << 16) | o : -1;
   }
   const int nxw = (p.xinstr + NW - 1 - wave) / NW, naw = ((p.AUw >> 8) + NW - 1 - wave) / NW;   // pieces of this wave
-  auto xpiece = [&](int n, int off, int chunk, int buf) {
+  // (qg: plane word of the slab's first word for this chunk's tap group; sc: the chunk's first channel; kleft: channels left)
+  auto xpiece = [&](int n, int off, int chunk, int buf, int qg, const float* sc, int kleft) {
     if (n < nxw && !(p.dbg == 4 && chunk)) {
-      const int klim = min(p.CK, p.K - chunk * p.CK) * p.SL;       // channels past K (last chunk) are zeros
-      const bool ok = off >= 0 && off < klim;
-      hglds16(ok ? (const void*)(srcb + (long)chunk * p.CK * p.SL + off) : (const void*)zsrc,
-              hlds + buf * p.xslab + (wave + n * NW) * 256);
+      const int c = off >> 16, q = qg + (off & 0xffff);
+      // channels past K (last chunk) and words outside the plane (rows above / below it) are zeros
+      const bool ok = off >= 0 && c < kleft && q >= 0 && q < p.SL;
+      hglds16(ok ? (const void*)(sc + (long)c * p.SL + q) : (const void*)zsrc, hlds + buf * p.xslab + (wave + n * NW) * 256);
     }
   };
   auto apiece = [&](int n, int chunk, int buf) {
@@ -94,17 +98,20 @@ __global__ __launch_bounds__(WM * WN * 64) void head_gemm_kernel(const HeadParam
       hglds16(reinterpret_cast<const uint4*>(p.wp) + (long)chunk * (p.AUw >> 2) + (wave + n * NW) * 64 + lane,
               hlds + 2 * p.xslab + buf * p.AUw + (wave + n * NW) * 256);
   };
-  // everything of a chunk at once (the first chunk; pieces beyond the chunk's steps)
+  // everything of a chunk at once
   auto stage_from = [&](int n0, int chunk, int buf) {
+    int cq = chunk, tg = 0;
+    if (MODE == 2) { cq = chunk / p.NG; tg = chunk - cq * p.NG; }
+    const int qg = SN * p0 - p.HALO + tg * p.grp_shift, kleft = p.K - cq * p.CK;
+    const float* sc = srcb + (long)cq * p.CK * p.SL;
 #pragma unroll
-    for (int n = 0; n < 2 * NT; ++n)
-      if (n >= n0) xpiece(n, so[n / NT][n % NT], chunk, buf);
-    const int xu4 = p.XS >> 2, used = SN * PXT + 2 * p.HALO, q0 = SN * p0 - p.HALO;
+    for (int n = 0; n < NSO; ++n)
+      if (n >= n0) xpiece(n, so[n], chunk, buf, qg, sc, kleft);
 #pragma unroll 1
-    for (int n = max(n0, 2 * NT); n < nxw; ++n) {          // (more X pieces than the table holds: not with plan_head's tiles)
+    for (int n = max(n0, NSO); n < nxw; ++n) {          // (more X pieces than the table holds: not with the planners' tiles)
       const int u = (wave + n * NW) * 64 + lane;
-      const int c = (int)(((unsigned)u * (unsigned)p.xmagic) >> 20), o = (u - c * xu4) * 4, q = q0 + o;
-      xpiece(n, (c < p.CK && o < used && q >= 0 && q < p.SL) ? c * p.SL + q : -1, chunk, buf);
+      const int c = (int)(((unsigned)u * (unsigned)p.xmagic) >> 20), o = (u - c * xu4) * 4;
+      xpiece(n, (c < p.CK && o < p.used) ? (c << 16) | o : -1, chunk, buf, qg, sc, kleft);
     }
 #pragma unroll 1
     for (int n = n0; n < naw; ++n) apiece(n, chunk, buf);
@@ -116,14 +123,25 @@ __global__ __launch_bounds__(WM * WN * 64) void head_gemm_kernel(const HeadParam
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[t][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  stage_from(0, 0, 0);
-  for (int chunk = 0; chunk < p.nChunks; ++chunk) {
-    const int buf = chunk & 1;
+  // tall backward-data: dx pixel q takes dY[q - dy W], which exists for dy in [q / W - (OH - 1), q / W] only -- tap groups
+  // that fall outside that interval for every pixel of the tile are skipped (57 % of the taps exist for T = 174)
+  int tg_lo = 0, ng = p.NG;
+  if (MODE == 2 && p.grp_shift < 0) {
+    const int W = -p.grp_shift / NT, OHm1 = p.SL / W - 1;
+    const int dy_hi = min(p.NG * NT - 1, (p0 + PXT - 1) / W), dy_lo = max(0, p0 / W - OHm1);
+    tg_lo = dy_lo / NT;
+    ng = max(1, dy_hi / NT - tg_lo + 1);
+  }
+  const int nch = (p.nChunks / p.NG) * ng;
+  auto real = [&](int i) { const int cq = i / ng; return cq * p.NG + tg_lo + (i - cq * ng); };   // i-th chunk this tile runs
+  stage_from(0, real(0), 0);
+  for (int ci = 0; ci < nch; ++ci) {
+    const int buf = ci & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();              // this chunk has landed everywhere; nobody still reads the other buffer
-    const bool more = chunk + 1 < p.nChunks && p.dbg < 2;
+    const bool more = ci + 1 < nch && p.dbg < 2;
     if (p.dbg == 3 || !INTER) {
-      if (more) stage_from(0, chunk + 1, buf ^ 1);
+      if (more) stage_from(0, real(ci + 1), buf ^ 1);
       if (p.dbg == 3) continue;
     }
     const float* xb = hlds + buf * p.xslab + g * p.XS + SN * (wn * NB * 16 + j);
@@ -153,14 +171,6 @@ __global__ __launch_bounds__(WM * WN * 64) void head_gemm_kernel(const HeadParam
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) b1[nb] = xb[kn * 4 * p.XS + SN * 16 * nb + toff];
         }
-        if (INTER && more) {
-          // (opaque to the optimiser: otherwise the address arithmetic of all 2 NT pieces is hoisted out of the kq loop and
-          // lives in ~100 registers)
-          int off = kq ? so[1][tap] : so[0][tap], n = kq * NT + tap;
-          asm volatile("" : "+v"(off), "+s"(n));
-          xpiece(n, off, chunk + 1, buf ^ 1);
-          apiece(n, chunk + 1, buf ^ 1);
-        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 1; t < MT; ++t)
@@ -173,7 +183,6 @@ __global__ __launch_bounds__(WM * WN * 64) void head_gemm_kernel(const HeadParam
         for (int nb = 0; nb < NB; ++nb) b0[nb] = b1[nb];
       }
     }
-    if (INTER && more) stage_from(nkq * NT, chunk + 1, buf ^ 1);
   }
 
   // lane (j, g) holds rows 4g .. 4g+3 of each 16-row tile at pixel column j of each pixel block
@@ -204,9 +213,9 @@ __global__ __launch_bounds__(WM * WN * 64) void head_gemm_kernel(const HeadParam
     }
 }
 
-template <int MT, int WM, int WN, int NT, bool FWD>
+template <int MT, int WM, int WN, int NT, int MODE>
 int head_launch_one(const HeadPlan& pl, const HeadParams& p, int B, hipStream_t s) {
-  auto k = head_gemm_kernel<MT, WM, WN, NT, FWD>;
+  auto k = head_gemm_kernel<MT, WM, WN, NT, MODE>;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); attr = true; }
   MPA_LAUNCH(k, dim3((unsigned)((long)B * pl.tilesP)), dim3(WM * WN * 64), pl.lds_bytes, s, p);
@@ -214,14 +223,18 @@ int head_launch_one(const HeadPlan& pl, const HeadParams& p, int B, hipStream_t 
 }
 
 int head_launch(const HeadPlan& pl, const HeadParams& p, int B, hipStream_t s) {
-#define MPA_HEAD_CASE(MT_, WM_, WN_, NT_, FWD_) \
-  if (pl.MT == MT_ && pl.WM == WM_ && pl.WN == WN_) return head_launch_one<MT_, WM_, WN_, NT_, FWD_>(pl, p, B, s)
+#define MPA_HEAD_CASE(MT_, WM_, WN_, NT_, MODE_) \
+  if (pl.MT == MT_ && pl.WM == WM_ && pl.WN == WN_ && pl.NT == NT_) return head_launch_one<MT_, WM_, WN_, NT_, MODE_>(pl, p, B, s)
   if (pl.mode == 0) {
-    MPA_HEAD_CASE(4, 1, 4, 9, true); MPA_HEAD_CASE(5, 1, 4, 9, true); MPA_HEAD_CASE(6, 1, 4, 9, true); MPA_HEAD_CASE(7, 1, 4, 9, true);
-    MPA_HEAD_CASE(4, 2, 4, 9, true); MPA_HEAD_CASE(5, 2, 4, 9, true); MPA_HEAD_CASE(6, 2, 4, 9, true); MPA_HEAD_CASE(7, 2, 4, 9, true);
-  } else {
-    MPA_HEAD_CASE(4, 2, 4, 3, false); MPA_HEAD_CASE(5, 2, 4, 3, false); MPA_HEAD_CASE(6, 2, 4, 3, false); MPA_HEAD_CASE(7, 2, 4, 3, false);
-    MPA_HEAD_CASE(5, 4, 2, 3, false); MPA_HEAD_CASE(6, 4, 2, 3, false); MPA_HEAD_CASE(7, 4, 2, 3, false);
+    MPA_HEAD_CASE(4, 1, 4, 9, 0); MPA_HEAD_CASE(5, 1, 4, 9, 0); MPA_HEAD_CASE(6, 1, 4, 9, 0); MPA_HEAD_CASE(7, 1, 4, 9, 0);
+    MPA_HEAD_CASE(4, 2, 4, 9, 0); MPA_HEAD_CASE(5, 2, 4, 9, 0); MPA_HEAD_CASE(6, 2, 4, 9, 0); MPA_HEAD_CASE(7, 2, 4, 9, 0);
+  } else if (pl.mode == 1) {
+    MPA_HEAD_CASE(4, 2, 4, 3, 1); MPA_HEAD_CASE(5, 2, 4, 3, 1); MPA_HEAD_CASE(6, 2, 4, 3, 1); MPA_HEAD_CASE(7, 2, 4, 3, 1);
+    MPA_HEAD_CASE(5, 4, 2, 3, 1); MPA_HEAD_CASE(6, 4, 2, 3, 1); MPA_HEAD_CASE(7, 4, 2, 3, 1);
+  } else {                      // tall filters, forward and backward-data
+    MPA_HEAD_CASE(4, 1, 4, 25, 2); MPA_HEAD_CASE(5, 1, 4, 25, 2);
+    MPA_HEAD_CASE(6, 1, 4, 15, 2); MPA_HEAD_CASE(7, 1, 4, 15, 2);
+    MPA_HEAD_CASE(4, 2, 4, 15, 2); MPA_HEAD_CASE(5, 2, 4, 15, 2); MPA_HEAD_CASE(6, 2, 4, 15, 2); MPA_HEAD_CASE(7, 2, 4, 15, 2);
   }
 #undef MPA_HEAD_CASE
   return MPA_ERR_UNSUPPORTED;
@@ -240,11 +253,21 @@ int head_params(const mpa_conv_desc* d, const HeadPlan& pl, HeadParams& p) {
     if ((int)(((unsigned long)u * (unsigned long)p.xmagic) >> 20) != (int)(u / xu4) || u * (long)p.xmagic >= (1L << 32))
       return MPA_ERR_UNSUPPORTED;
   p.AUw = (int)pl.AUw;
-  const int OW = d->W / 3;
   { const char* e = getenv("MPA_HEAD_DEBUG"); p.dbg = e ? atoi(e) : 0; }
-  for (int t = 0; t < 9; ++t) p.tapoff[t] = 0;
-  if (pl.mode == 0) for (int dy = 0; dy < 3; ++dy) for (int dx = 0; dx < 3; ++dx) p.tapoff[dy * 3 + dx] = dy * d->W + dx;
-  else for (int dy = 0; dy < 3; ++dy) p.tapoff[dy] = (2 - dy) * OW;
+  for (int t = 0; t < 25; ++t) p.tapoff[t] = 0;
+  p.NG = 1; p.grp_shift = 0;
+  if (pl.mode == 0) {
+    p.used = 3 * pl.PXT + 2 * pl.HALO;
+    for (int dy = 0; dy < 3; ++dy) for (int dx = 0; dx < 3; ++dx) p.tapoff[dy * 3 + dx] = dy * d->W + dx;
+  } else if (pl.mode == 1) {
+    p.used = pl.PXT + 2 * pl.HALO;
+    for (int dy = 0; dy < 3; ++dy) p.tapoff[dy] = (2 - dy) * (d->W / 3);
+  } else {
+    p.used = pl.PXT + (pl.NT - 1) * d->W;
+    p.NG = d->kh / pl.NT;
+    if (pl.mode == 2) { p.grp_shift = pl.NT * d->W; for (int t = 0; t < pl.NT; ++t) p.tapoff[t] = t * d->W; }
+    else { p.grp_shift = -pl.NT * d->W; for (int t = 0; t < pl.NT; ++t) p.tapoff[t] = (pl.NT - 1 - t) * d->W; }
+  }
   return MPA_OK;
 }
 
@@ -468,6 +491,31 @@ int mpa_conv_head_bwd_data(const mpa_conv_desc* d, const float* dy, const float*
   if (rc) return rc;
   p.src = dy; p.wp = wp; p.bias = nullptr; p.out = dx;
   p.srcBS = (long)d->Cout * pl.SL; p.outPS = (long)d->H * d->W; p.outBS = (long)d->Cin * p.outPS;
+  p.act = MPA_ACT_NONE; p.slope = 0.f;
+  return head_launch(pl, p, d->B, s);
+}
+
+int mpa_conv_tall_fwd(const mpa_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, int act, float slope,
+                      hipStream_t s) {
+  const HeadPlan pl = plan_tall(d, 2);
+  if (!pl.ok) return MPA_ERR_UNSUPPORTED;
+  HeadParams p{};
+  const int rc = head_params(d, pl, p);
+  if (rc) return rc;
+  p.src = x; p.wp = wp; p.bias = bias; p.out = y;
+  p.srcBS = (long)d->Cin * pl.SL; p.outBS = (long)d->Cout * pl.P; p.outPS = 0;
+  p.act = act; p.slope = slope;
+  return head_launch(pl, p, d->B, s);
+}
+
+int mpa_conv_tall_bwd_data(const mpa_conv_desc* d, const float* dy, const float* wp, float* dx, hipStream_t s) {
+  const HeadPlan pl = plan_tall(d, 3);
+  if (!pl.ok) return MPA_ERR_UNSUPPORTED;
+  HeadParams p{};
+  const int rc = head_params(d, pl, p);
+  if (rc) return rc;
+  p.src = dy; p.wp = wp; p.bias = nullptr; p.out = dx;
+  p.srcBS = (long)d->Cout * pl.SL; p.outBS = (long)d->Cin * pl.P; p.outPS = 0;
   p.act = MPA_ACT_NONE; p.slope = 0.f;
   return head_launch(pl, p, d->B, s);
 }

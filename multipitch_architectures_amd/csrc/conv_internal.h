@@ -16,3 +16,7 @@ int mpa_conv_head_bwd_data(const mpa_conv_desc* d, const float* dy, const float*
 int64_t mpa_conv_head_wgrad_workspace(const mpa_conv_desc* d);
 int mpa_conv_head_bwd_weight(const mpa_conv_desc* d, const float* x, const float* dy, float* dw, float* db, void* workspace,
                              int64_t workspace_bytes, hipStream_t s);
+// tall (kh,1) filters (conv3 at T > 75) on the same GEMM kernel: conv_head.hip, conv_plan.h: plan_tall
+int mpa_conv_tall_fwd(const mpa_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, int act, float slope,
+                      hipStream_t s);
+int mpa_conv_tall_bwd_data(const mpa_conv_desc* d, const float* dy, const float* wp, float* dx, hipStream_t s);

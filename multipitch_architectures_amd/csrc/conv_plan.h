@@ -636,6 +636,47 @@ inline HeadPlan plan_head(const mpa_conv_desc* d, int mode) {
   return pl;
 }
 
+// Tall filters -- conv3's Conv2d(n1, n2, (75,1)) on patches longer than 75 frames (unet_cnns.py:545-549, basic_cnns.py:397-401;
+// training / evaluation on segments, T = 174 in the torchinfo summaries) -- run on the same GEMM kernel (conv_head.hip,
+// MODE 2): with one column of taps, output pixel p = oy*W + x reads input word p + dy*W, again linear in p.  The kh taps go
+// in groups of NT (25, or 15 above 5 output-row tiles: the filter chunk has to fit LDS next to the slab); a chunk = (4
+// channels, tap group), its slab = the group's window [p0 + t0*W, p0 + PXT + (t0 + NT - 1)*W) of the plane.  Backward-data =
+// the same with the windows running upwards (p - dy*W) and zero pages above / below the dY plane.  HeadPlan fields as above
+// (mode 2 forward, 3 backward-data); NG tap groups.
+inline HeadPlan plan_tall(const mpa_conv_desc* d, int mode, int* NGout = nullptr) {
+  HeadPlan pl{};
+  pl.ok = false;
+  const int OH = d->H - d->kh + 1;
+  if (d->kw != 1 || d->sh != 1 || d->sw != 1 || d->ph != 0 || d->pw != 0 || d->kh < 30 || OH < 2 || d->W % 4 || d->Cin < 16 ||
+      d->Cout < 16 || getenv("MPA_TALL_OFF"))
+    return pl;
+  const int rows = mode == 2 ? d->Cout : d->Cin;
+  const int tiles = (int)mpa_cdiv(rows, 16);
+  if (tiles < 2 || tiles > 14) return pl;
+  if (tiles <= 7) { pl.WM = 1; pl.MT = std::max(tiles, 4); }
+  else { pl.WM = 2; pl.MT = std::max((int)mpa_cdiv(tiles, 2), 4); }
+  pl.MTT = pl.WM * pl.MT;
+  pl.NT = pl.MTT <= 5 ? 25 : 15;
+  if (d->kh % pl.NT) return pl;
+  const int NG = d->kh / pl.NT;
+  if (NGout) *NGout = NG;
+  pl.mode = mode; pl.WN = 4; pl.NB = 5; pl.SN = 1;
+  pl.PXT = pl.WN * pl.NB * 16;
+  if (mode == 2) { pl.K = d->Cin; pl.Mrows = d->Cout; pl.P = OH * d->W; pl.SL = d->H * d->W; pl.HALO = 0; }
+  else { pl.K = d->Cout; pl.Mrows = d->Cin; pl.P = d->H * d->W; pl.SL = OH * d->W; pl.HALO = (pl.NT - 1) * d->W; }
+  if (pl.SL % 4 || pl.P % 4) return pl;
+  pl.tilesP = (int)mpa_cdiv(pl.P, pl.PXT);
+  pl.XS = round_mod(pl.PXT + (pl.NT - 1) * d->W, 32, 16);
+  if (pl.XS > 65535) return pl;
+  pl.CK = 4;
+  pl.AUw = mpa_cdiv((long)pl.NT * pl.MTT * 64, 256) * 256;
+  pl.lds_bytes = 2 * ((size_t)mpa_cdiv((long)pl.CK * (pl.XS / 4), 64) * 256 + (size_t)pl.AUw) * 4;
+  if (pl.lds_bytes > 150 * 1024) return pl;
+  pl.nChunks = (int)mpa_cdiv(pl.K, pl.CK) * NG;
+  pl.ok = true;
+  return pl;
+}
+
 // backward-weight: a workgroup (4 waves x 16 input channels, MT cout tiles, all 9 taps in 36*MT accumulator registers) owns
 // work items (image, column segment of SEG output pixels, block of rows) and walks the rows of an item top to bottom with a
 // ring of three input-row segments in LDS: every input row is staged once and serves the three filter rows of the output

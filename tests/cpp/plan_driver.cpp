@@ -20,6 +20,12 @@ static void one(const char* name, int B, int Cin, int H, int W, int Cout, int kh
     if (h.ok) printf("%s head%d ok=1 MT=%d WM=%d WN=%d CK=%d chunks=%d NT=%d rows=%d PXT=%d tilesP=%d XS=%d P=%d lds=%zu\n", name, mode,
                      h.MT, h.WM, h.WN, h.CK, h.nChunks, h.NT, h.Mrows, h.PXT, h.tilesP, h.XS, h.P, h.lds_bytes);
   }
+  for (int mode = 2; mode < 4; ++mode) {          // tall (kh,1) filters on the same kernel
+    int NG = 0;
+    const HeadPlan h = plan_tall(&d, mode, &NG);
+    if (h.ok) printf("%s tall%d ok=1 MT=%d WM=%d WN=%d CK=%d chunks=%d NT=%d NG=%d rows=%d PXT=%d tilesP=%d XS=%d P=%d lds=%zu\n", name,
+                     mode - 2, h.MT, h.WM, h.WN, h.CK, h.nChunks, h.NT, NG, h.Mrows, h.PXT, h.tilesP, h.XS, h.P, h.lds_bytes);
+  }
   {
     const HeadWgPlan h = plan_head_wgrad(&d);
     if (h.ok) printf("%s headwg ok=1 MT=%d coGroups=%d chGroups=%d S=%d NCS=%d SEG=%d NRB=%d RB=%d itemsPer=%ld XUs=%d DUs=%d lds=%zu\n",
@@ -50,6 +56,8 @@ int main() {
   one("conv2_80", 256, 128, 75, 216, 80, 3, 3, 1, 3, 1, 0);
   one("conv2_200", 256, 128, 75, 216, 200, 3, 3, 1, 3, 1, 0);
   one("conv2_80_b32", 32, 128, 75, 216, 80, 3, 3, 1, 3, 1, 0);
+  one("conv3_T174", 64, 80, 174, 72, 50, 75, 1, 1, 1, 0, 0);
+  one("conv3_T75", 64, 80, 75, 72, 50, 75, 1, 1, 1, 0, 0);
   one("strided_unsupported", 4, 8, 20, 20, 8, 3, 3, 2, 2, 1, 1);
   return 0;
 }

@@ -72,3 +72,14 @@ def test_head_conv2_and_fold_plans(plans):
         p = plans[("prefilt", k)]
         assert (p["C0"], p["R"], p["V"]) == (64, 6, 2)                           # 70 = 64 + 6 rows x 2
     assert ("upconv4b", "foldf") not in plans and ("conv2_80", "foldf") not in plans
+
+
+def test_tall_filter_plans(plans):
+    """conv3's (75,1) filters at T > 75 (conv_plan.h: plan_tall): tap groups of 25 on the head GEMM kernel; at T = 75 the layer is a
+    GEMM (ops.conv2d) and no tall plan exists"""
+    f, b = plans[("conv3_T174", "tall0")], plans[("conv3_T174", "tall1")]
+    assert (f["MT"], f["WM"], f["NT"], f["NG"], f["rows"], f["P"]) == (4, 1, 25, 3, 50, 100 * 72)
+    assert (b["MT"], b["WM"], b["NT"], b["NG"], b["rows"], b["P"]) == (5, 1, 25, 3, 80, 174 * 72)
+    assert f["XS"] % 32 == 16 and f["lds"] <= 150 * 1024 and b["lds"] <= 150 * 1024
+    assert f["chunks"] == 20 * 3 and b["chunks"] == 13 * 3
+    assert ("conv3_T75", "tall0") not in plans and ("conv3_T75", "tall1") not in plans

@@ -115,3 +115,41 @@ def test_head_forward_goes_to_the_generic_kernel_for_small_launches(dev, monkeyp
     assert _plan((64, 128, 75, 216, 80), 0).startswith("head_gemm<5,1,4>")
     assert _plan((32, 128, 75, 216, 80), 1).startswith("head_gemm<6,4,2>")  # backward passes: at every batch
     assert _plan((32, 128, 75, 216, 80), 2).startswith("head_wgrad<5>")
+
+
+# ---------------------------------------------------------------------------------------------- tall filters (conv3, T > 75)
+# Conv2d(n1, n2, (75,1)) on patches longer than 75 frames (unet_cnns.py:545-549, basic_cnns.py:397-401): forward and
+# backward-data on the same GEMM kernel (tap groups of 25 / 15), backward-weight on the generic kernel.
+# (B, Cin, H, W, Cout) and the kernels expected for (forward, backward-data)
+TALL_CASES = [
+    ((2, 80, 174, 72, 50), ("tall_gemm<4,1,4>", "tall_gemm<5,1,4>")),        # SAUnet:L at T = 174: 100 output frames
+    ((1, 150, 100, 72, 100), ("tall_gemm<7,1,4>", "tall_gemm<5,2,4>")),      # Unet:L at T = 100: 7 / 10 row tiles, 15-tap groups
+    ((1, 200, 90, 72, 150), ("tall_gemm<5,2,4>", "tall_gemm<7,2,4>")),       # BLUnet:XXL channels
+    ((2, 32, 76, 24, 64), ("tall_gemm<4,1,4>", "tall_gemm<4,1,4>")),         # two output rows, narrow plane
+    ((2, 20, 100, 72, 10), ("fwd<", "fwd<")),                                # CNN:XS: too few channels, the generic kernels
+]
+
+
+@pytest.mark.parametrize("case,kernels", TALL_CASES, ids=lambda c: "x".join(map(str, c)) if isinstance(c[0], int) else None)
+def test_tall_conv_matches_float64(dev, case, kernels):
+    B, Cin, H, W, Cout = case
+    d = L.ConvDesc(B, Cin, H, W, Cout, 75, 1, 1, 1, 0, 0)
+    buf = ctypes.create_string_buffer(512)
+    for mode, want in enumerate(kernels):
+        assert L.load().mpa_conv2d_describe_plan(ctypes.byref(d), mode, buf, 512) == 0
+        assert buf.value.decode().startswith(want), (mode, buf.value)
+    x = _rand((B, Cin, H, W), 1)
+    w = _rand((Cout, Cin, 75, 1), 2, (2.0 / (Cin * 75)) ** 0.5)
+    b = _rand((Cout,), 3, 0.1)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    zr = F.conv2d(xr, wr, br)
+    yr = F.leaky_relu(zr, 0.3)
+    gy = _rand(tuple(yr.shape), 4) * (zr.detach().abs() > 1e-4).float()
+    yr.backward(gy.double())
+    xg, wg, bg = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    y = ops.conv2d(xg, wg, bg, (1, 1), (0, 0), ops.ACT_LRELU, 0.3)
+    y.backward(gy.to(dev))
+    for a, ref, rtol, what in ((y, yr.detach(), 2e-5, "y"), (xg.grad, xr.grad, 2e-5, "dx"), (wg.grad, wr.grad, 5e-5, "dw"),
+                               (bg.grad, br.grad, 5e-5, "db")):
+        err = float((a.detach().cpu().double() - ref).abs().max())
+        assert err <= rtol * float(ref.abs().max()), f"{what}: err {err:.3e} vs scale {float(ref.abs().max()):.3e}"
