@@ -28,3 +28,6 @@ def run(name, fn, mode):
     print(f"{name:6s} {t:7.3f} ms {fl / t / 1e9:6.1f} TF  {buf.value.decode()[:100]}", flush=True)
 run("fwd", lambda: lib.mpa_conv2d_fwd(ctypes.byref(d), P(x), P(wp[0]), None, P(y), 2, ctypes.c_float(0.3), st), 0)
 run("dgrad", lambda: lib.mpa_conv2d_bwd_data(ctypes.byref(d), P(gy), P(wp[1]), P(dx), st), 1)
+dw = torch.empty_like(w); db = torch.empty(Cout, device=dev)
+n = lib.mpa_conv2d_bwd_weight_workspace(ctypes.byref(d)); ws = torch.empty(n // 4, device=dev)
+run("wgrad", lambda: lib.mpa_conv2d_bwd_weight(ctypes.byref(d), P(x), P(gy), P(dw), P(db), P(ws), n, st), 2)
