@@ -186,6 +186,12 @@ int mpa_upcat_bwd(const float* dout, float* dx1, float* dskip, int B, int C1, in
  * nn.LeakyReLU / nn.ReLU / nn.Sigmoid / nn.Dropout / residual adds                                         */
 int mpa_act_fwd(const float* x, float* y, int64_t n, int act, float slope, void* stream);
 int mpa_act_bwd(const float* dy, const float* x, float* dx, int64_t n, int act, float slope, void* stream);
+/* nn.LogSoftmax(dim=1) over the channels of cat([a, b], dim=3): a (B,C,R,Wa), b (B,C,R,Wb) or NULL with Wb = 0, y (B,C,R,Wa+Wb)
+ * -- the output stage of basic_cnn_segm_logsoftmax / basic_cnn_segm_blank_logsoftmax (basic_cnns.py:254-255, 331-338).
+ * Backward from y: da / db = dy - exp(y) * sum_c dy. */
+int mpa_logsoftmax_cat_fwd(const float* a, const float* b, float* y, int B, int C, int R, int Wa, int Wb, void* stream);
+int mpa_logsoftmax_cat_bwd(const float* dy, const float* y, float* da, float* db, int B, int C, int R, int Wa, int Wb,
+                           void* stream);
 /* rng_state (device memory): [0] seed, [1] base offset of the current training step; `offset` = position of this call's
  * elements inside the step.  Element i draws from the counter-based stream at rng_state[1] + offset + i.        */
 int mpa_dropout(const float* x, float* y, int64_t n, float p, const uint64_t* rng_state, uint64_t offset, void* stream);

@@ -550,6 +550,50 @@ int poolrows_bwd_launch(const float* dout, const int8_t* which, float* dh, long 
   }
   return mpa_launch_status();
 }
+
+// nn.LogSoftmax(dim=1) over the channels of cat([a, b], dim=3) -- the output stage of basic_cnn_segm_logsoftmax /
+// basic_cnn_segm_blank_logsoftmax (basic_cnns.py:254-255, 331-338).  a (B,C,R,Wa), b (B,C,R,Wb) or absent; one thread per
+// (b, r, w) walks the C channels (a handful) three times: max, sum of exponentials, output.
+__global__ void logsoftmax_cat_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long n,
+                                          int C, int R, int Wa, int Wb) {
+  const int W = Wa + Wb;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int w = (int)(i % W);
+    const long t = i / W;
+    const int r = (int)(t % R);
+    const long bb = t / R;
+    const bool ina = w < Wa;
+    const float* src = ina ? a + (bb * C * R + r) * (long)Wa + w : b + (bb * C * R + r) * (long)Wb + (w - Wa);
+    const long cs = (long)R * (ina ? Wa : Wb);
+    float m = -INFINITY;
+    for (int c = 0; c < C; ++c) m = fmaxf(m, src[c * cs]);
+    float sum = 0.f;
+    for (int c = 0; c < C; ++c) sum += expf(src[c * cs] - m);
+    const float lse = m + logf(sum);
+    float* dst = y + (bb * C * R + r) * (long)W + w;
+    for (int c = 0; c < C; ++c) dst[(long)c * R * W] = src[c * cs] - lse;
+  }
+}
+
+// da / db = dy - exp(y) * sum_c dy
+__global__ void logsoftmax_cat_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ da,
+                                          float* __restrict__ db, long n, int C, int R, int Wa, int Wb) {
+  const int W = Wa + Wb;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int w = (int)(i % W);
+    const long t = i / W;
+    const int r = (int)(t % R);
+    const long bb = t / R;
+    const long o = (bb * C * R + r) * (long)W + w, ys = (long)R * W;
+    float g = 0.f;
+    for (int c = 0; c < C; ++c) g += dy[o + c * ys];
+    const bool ina = w < Wa;
+    float* dst = ina ? da + (bb * C * R + r) * (long)Wa + w : db + (bb * C * R + r) * (long)Wb + (w - Wa);
+    const long cs = (long)R * (ina ? Wa : Wb);
+    for (int c = 0; c < C; ++c) dst[c * cs] = dy[o + c * ys] - expf(y[o + c * ys]) * g;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -565,6 +609,20 @@ const char* mpa_strerror(int code) {
   }
 }
 int mpa_version(void) { return 1; }
+int mpa_logsoftmax_cat_fwd(const float* a, const float* b, float* y, int B, int C, int R, int Wa, int Wb, void* stream) {
+  if (!a || !y || B <= 0 || C <= 0 || R <= 0 || Wa <= 0 || Wb < 0 || (Wb > 0 && !b)) return MPA_ERR_ARG;
+  const long n = (long)B * R * (Wa + Wb);
+  MPA_LAUNCH(logsoftmax_cat_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, n, C, R, Wa, Wb);
+  return mpa_launch_status();
+}
+int mpa_logsoftmax_cat_bwd(const float* dy, const float* y, float* da, float* db, int B, int C, int R, int Wa, int Wb,
+                           void* stream) {
+  if (!dy || !y || !da || B <= 0 || C <= 0 || R <= 0 || Wa <= 0 || Wb < 0 || (Wb > 0 && !db)) return MPA_ERR_ARG;
+  const long n = (long)B * R * (Wa + Wb);
+  MPA_LAUNCH(logsoftmax_cat_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, dy, y, da, db, n, C, R, Wa, Wb);
+  return mpa_launch_status();
+}
+
 
 int mpa_act_fwd(const float* x, float* y, int64_t n, int act, float slope, void* stream) {
   if (!x || !y) return MPA_ERR_ARG;

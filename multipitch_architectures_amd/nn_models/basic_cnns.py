@@ -6,7 +6,7 @@ multipitch_architectures_amd.ops.
 """
 import torch.nn as nn
 
-from .layers import (Conv2d, ConvActPoolDrop, Dropout, LayerNorm, LeakyReLU, MaxPool2d, OutputHead, Sigmoid)
+from .layers import (Conv2d, ConvActPoolDrop, Dropout, LayerNorm, LeakyReLU, LogSoftmax, MaxPool2d, OutputHead, Sigmoid)
 from .. import ops
 
 
@@ -131,4 +131,72 @@ class basic_cnn_pool(nn.Module):
         conv2_lrelu = self.conv2(conv1_lrelu)
         conv3_lrelu = self.conv3(conv2_lrelu)
         y_pred = self.conv4(conv3_lrelu)
+        return y_pred
+
+
+class _LogSoftmaxHead(nn.Sequential):
+    """conv4 of basic_cnn_segm_logsoftmax: Conv 1x1 + LeakyReLU + Dropout + Conv 1xk + LogSoftmax(dim=1) (basic_cnns.py:249-255)"""
+
+    def forward(self, x):
+        conv_a, act, drop, conv_b, lsm = list(self)
+        return lsm(conv_b(drop(conv_a(x, act.act, act.slope))))
+
+
+class basic_cnn_segm_logsoftmax(nn.Module):
+    """basic_cnns.py:198-263 -- basic_cnn_segm_sigmoid with n_ch_out output channels and a log-softmax across them instead of
+    the sigmoid: (B,6,T>=75,216) -> (B,n_ch_out,T-74,n_bins_out) log-probabilities.  No experiment script uses it."""
+
+    def __init__(self, n_chan_input=6, n_chan_layers=[20, 20, 10, 1], n_ch_out=2, n_bins_in=216, n_bins_out=12, a_lrelu=0.3,
+                 p_dropout=0.2):
+        super().__init__()
+        n_in, n_ch = n_chan_input, n_chan_layers
+        last_kernel_size = n_bins_in // 3 + 1 - n_bins_out
+        self.layernorm = LayerNorm(normalized_shape=[n_in, n_bins_in])
+        self.conv1 = _prefilter(n_in, n_ch[0], a_lrelu, p_dropout)
+        self.conv2, self.conv3, _ = _head(n_ch[0], n_ch, n_bins_in, n_bins_out, a_lrelu, p_dropout)
+        self.conv4 = _LogSoftmaxHead(
+            Conv2d(n_ch[2], n_ch[3], kernel_size=(1, 1), padding=(0, 0), stride=(1, 1)),
+            LeakyReLU(negative_slope=a_lrelu),
+            Dropout(p=p_dropout),
+            Conv2d(n_ch[3], n_ch_out, kernel_size=(1, last_kernel_size), padding=(0, 0), stride=(1, 1)),
+            LogSoftmax(dim=1))
+
+    def forward(self, x):
+        x_norm = self.layernorm.forward_cf(x)
+        conv1_lrelu = self.conv1(x_norm)
+        conv2_lrelu = self.conv2(conv1_lrelu)
+        conv3_lrelu = self.conv3(conv2_lrelu)
+        y_pred = self.conv4(conv3_lrelu)
+        return y_pred
+
+
+class basic_cnn_segm_blank_logsoftmax(nn.Module):
+    """basic_cnns.py:267-340 -- as above with an extra "blank" column (MCTC): conv5b spans all 72 bins, its single column is
+    stacked in front of conv5a's n_bins_out columns and the log-softmax runs across the n_ch_out channels of the stack:
+    (B,6,T>=75,216) -> (B,n_ch_out,T-74,1+n_bins_out).  No experiment script uses it."""
+
+    def __init__(self, n_chan_input=6, n_chan_layers=[20, 20, 10, 1], n_ch_out=2, n_bins_in=216, n_bins_out=12, a_lrelu=0.3,
+                 p_dropout=0.2):
+        super().__init__()
+        n_in, n_ch = n_chan_input, n_chan_layers
+        last_kernel_size = n_bins_in // 3 + 1 - n_bins_out
+        self.layernorm = LayerNorm(normalized_shape=[n_in, n_bins_in])
+        self.conv1 = _prefilter(n_in, n_ch[0], a_lrelu, p_dropout)
+        self.conv2, self.conv3, _ = _head(n_ch[0], n_ch, n_bins_in, n_bins_out, a_lrelu, p_dropout)
+        self.conv4 = ConvActPoolDrop(
+            Conv2d(n_ch[2], n_ch[3], kernel_size=(1, 1), padding=(0, 0), stride=(1, 1)),
+            LeakyReLU(negative_slope=a_lrelu),
+            Dropout(p=p_dropout))
+        self.conv5a = Conv2d(n_ch[3], n_ch_out, kernel_size=(1, last_kernel_size), padding=(0, 0), stride=(1, 1))
+        self.conv5b = Conv2d(n_ch[3], n_ch_out, kernel_size=(1, 72), padding=(0, 0), stride=(1, 1))
+        self.logsoftmax7 = LogSoftmax(dim=1)
+
+    def forward(self, x):
+        x_norm = self.layernorm.forward_cf(x)
+        conv1_lrelu = self.conv1(x_norm)
+        conv2_lrelu = self.conv2(conv1_lrelu)
+        conv3_lrelu = self.conv3(conv2_lrelu)
+        conv4_lrelu = self.conv4(conv3_lrelu)
+        # torch.cat((conv5b(.), conv5a(.)), dim=3) and the log-softmax over dim 1 in one kernel
+        y_pred = self.logsoftmax7(self.conv5b(conv4_lrelu), self.conv5a(conv4_lrelu))
         return y_pred

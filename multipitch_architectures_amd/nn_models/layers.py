@@ -189,6 +189,19 @@ class Sigmoid(_Pointwise):
     act = ops.ACT_SIGMOID
 
 
+class LogSoftmax(nn.Module):
+    """nn.LogSoftmax(dim=1) of a (B,C,R,W) tensor (basic_cnns.py:255, 331) -- only the channel axis is built."""
+
+    def __init__(self, dim=1):
+        super().__init__()
+        if dim != 1:
+            raise NotImplementedError("only nn.LogSoftmax(dim=1), the one the reference uses, is built")
+        self.dim = dim
+
+    def forward(self, x, other=None):
+        return ops.logsoftmax_cat(x, other)
+
+
 class ELU(_Pointwise):
     """nn.ELU(alpha=1.0) -- double_conv's alt_order branch (unet_cnns.py:60-70)"""
     act = ops.ACT_ELU

@@ -814,6 +814,40 @@ def add(a, b):
     return AddFn.apply(a, b)
 
 
+class LogSoftmaxCatFn(torch.autograd.Function):
+    """nn.LogSoftmax(dim=1)(torch.cat([a, b], dim=3)) -- b may be None (basic_cnns.py:254-255, 331-338)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a = _c(a, "log-softmax input")
+        b = _c(b, "log-softmax input") if b is not None else None
+        B, C, R, Wa = a.shape
+        Wb = 0
+        if b is not None:
+            if b.shape[:3] != a.shape[:3]:
+                raise RuntimeError(f"logsoftmax_cat: shapes {tuple(a.shape)} and {tuple(b.shape)} differ outside the last axis")
+            Wb = b.shape[3]
+        y = torch.empty((B, C, R, Wa + Wb), dtype=torch.float32, device=a.device)
+        _chk(_lib().mpa_logsoftmax_cat_fwd(_p(a), _p(b), _p(y), B, C, R, Wa, Wb, _s()), "mpa_logsoftmax_cat_fwd")
+        ctx.save_for_backward(y)
+        ctx.geom = (B, C, R, Wa, Wb)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        B, C, R, Wa, Wb = ctx.geom
+        dy = _c(dy, "log-softmax grad")
+        da = torch.empty((B, C, R, Wa), dtype=torch.float32, device=dy.device)
+        db = torch.empty((B, C, R, Wb), dtype=torch.float32, device=dy.device) if Wb else None
+        _chk(_lib().mpa_logsoftmax_cat_bwd(_p(dy), _p(y), _p(da), _p(db), B, C, R, Wa, Wb, _s()), "mpa_logsoftmax_cat_bwd")
+        return da, db
+
+
+def logsoftmax_cat(a, b=None):
+    return LogSoftmaxCatFn.apply(a, b)
+
+
 class TransposeAddFn(torch.autograd.Function):
     """x (B,R,C) -> (B,C,R), optionally adding a positional table pe (C,R) laid out like the output."""
 

@@ -41,6 +41,22 @@ def sample_idx(n, k=16):
     return np.unique(np.linspace(0, n - 1, min(k, n)).astype(np.int64))
 
 
+def logsoftmax_weights(shape, dtype):
+    """fixed pattern for the linear loss of the log-softmax classes (their outputs are log-probabilities: no BCE)"""
+    n = int(np.prod(shape))
+    return torch.cos(torch.arange(n, dtype=torch.float64) * 0.37).reshape(shape).to(dtype)
+
+
+def variant_loss(name, res, y):
+    if "logsoftmax" in name:
+        return (res * logsoftmax_weights(tuple(res.shape), res.dtype)).mean()
+    two = isinstance(res, tuple)
+    loss = torch.nn.BCELoss()(res[0] if two else res, y)
+    if two:      # a loss that reaches the polyphony head whatever its width: mean of its (ReLU) output
+        loss = loss + res[1].mean() / 25.0
+    return loss
+
+
 def main():
     for name, kwargs in VARIANT_CONFIGS.items():
         B, T = 3, 75
@@ -65,9 +81,7 @@ def main():
                 m.p = 0.0
         model.train()
         res = model(x)
-        loss = torch.nn.BCELoss()(res[0] if two else res, y)
-        if two:      # a loss that reaches the polyphony head whatever its width: mean of its (ReLU) output
-            loss = loss + res[1].mean() / 25.0
+        loss = variant_loss(name, res, y)
         loss.backward()
         out["train.loss"] = np.array(loss.item())
         out["train.y"] = (res[0] if two else res).detach().numpy()
@@ -87,9 +101,7 @@ def main():
                 m.pe = m.pe.double()
         m64.train()
         r64 = m64(x.double())
-        l64 = torch.nn.BCELoss()(r64[0] if two else r64, y.double())
-        if two:
-            l64 = l64 + r64[1].mean() / 25.0
+        l64 = variant_loss(name, r64, y.double())
         l64.backward()
         out["train.loss64"] = np.array(l64.item())
         for k, p in m64.named_parameters():
