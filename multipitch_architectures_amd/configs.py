@@ -98,6 +98,7 @@ VARIANT_CONFIGS = {
     "simple_u_net_polyphony_classif": dict(_VT, num_polyphony_steps=24),
     "simple_u_net_doubleselfattn_polyphony": dict(_VT, **_VA),
     "simple_u_net_doubleselfattn_polyphony_classif": dict(_VT, **_VA, num_polyphony_steps=24),
+    "basic_cnn": dict(n_chan_layers=[8, 6, 5, 4], n_bins_out=72),
     "basic_cnn_pool": dict(n_chan_layers=[8, 6, 5, 4], n_bins_out=72),
     "basic_cnn_segm_logsoftmax": dict(n_chan_layers=[8, 6, 5, 4], n_ch_out=3, n_bins_out=72),
     "basic_cnn_segm_blank_logsoftmax": dict(n_chan_layers=[8, 6, 5, 4], n_ch_out=3, n_bins_out=72),

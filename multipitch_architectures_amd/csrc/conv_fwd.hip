@@ -560,6 +560,9 @@ __device__ __forceinline__ float conv_pack_value(const PackParams& p, const Pack
         v = p.w[(((long)ci * p.Cin_w + q.co_off + cc) * p.kh_w + (p.kh_w - 1 - dyo)) * p.kw_w + (p.kw_w - 1 - dx)];
     } else if (!q.xphase) {
       v = p.w[(((long)ci * p.Cin_w + q.co_off + co) * p.kh_w + (p.kh_w - 1 - dy)) * p.kw_w + (p.kw_w - 1 - dx)];
+    } else if (q.xphase == 2) {          // stride == kernel both ways: cout' = (cin*kh + v)*kw + q, a 1x1 convolution
+      const int nph = p.kh_w * p.kw_w, cc = co / nph, ph = co - cc * nph;
+      v = p.w[((long)ci * p.Cin_w + cc) * nph + ph];
     } else {
       const int cc = co / p.kw_w, ph = co - cc * p.kw_w;    // cout' = cin*kw + dx phase (see the epilogue)
       v = p.w[(((long)ci * p.Cin_w + cc) * p.kh_w + (p.kh_w - 1 - dy)) * p.kw_w + ph];
@@ -713,7 +716,7 @@ static int pack_params(const mpa_conv_desc* d, int mode, const float* w, float* 
     if (!g.ok) return MPA_ERR_UNSUPPORTED;
     pl = plan_bwd_data(d, g);
     if (!pl.ok) return MPA_ERR_UNSUPPORTED;
-    pack_dims(p.a, pl, g.Cin, g.Cout, g.kh, g.kw, g.xphase ? 1 : 0, g.yphase, 0);
+    pack_dims(p.a, pl, g.Cin, g.Cout, g.kh, g.kw, g.xyphase ? 2 : (g.xphase ? 1 : 0), g.yphase, 0);
   }
   p.b.total = 0;
   p.total = p.a.total;
@@ -831,6 +834,13 @@ int mpa_conv2d_bwd_data(const mpa_conv_desc* d, const float* dy, const float* w_
     return conv_fwd_impl(d->B, g.Cin, g.H, g.W, g.Cout, g.kh, g.kw, g.sh, 1, g.ph, g.pw, dy, w_packed, nullptr, dx,
                          MPA_ACT_NONE, 0.f, inBS, inCS, d->W, 1, d->Cin, (hipStream_t)stream, true, g.Hplan, g.yphase,
                          d->H);
+  }
+  if (g.xyphase) {
+    const int OH = (d->H - d->kh) / d->sh + 1, OW = (d->W - d->kw) / d->sw + 1;
+    if (OH * d->sh != d->H || OW * d->sw != d->W)          // rows / columns behind the last window: no gradient
+      if (mpa_zero_async(dx, sizeof(float) * (size_t)d->B * (size_t)inBS, (hipStream_t)stream) != MPA_OK) return MPA_ERR_LAUNCH;
+    return conv_fwd_impl(d->B, g.Cin, g.H, g.W, g.Cout, 1, 1, 1, 1, 0, 0, dy, w_packed, nullptr, dx, MPA_ACT_NONE, 0.f, inBS, inCS,
+                         d->W, d->sw, d->Cin, (hipStream_t)stream, true, 0, d->sh, d->H);
   }
   if (!g.xphase) {
     // output of the derived conv has size H x W again

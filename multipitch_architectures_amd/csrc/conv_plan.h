@@ -178,6 +178,7 @@ FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
 
 struct BwdDataGeom {
   bool ok, xphase;
+  bool xyphase;                          // stride == kernel in both directions: phases (v, q) of a 1x1 convolution
   int yphase;                            // V > 1: V output rows per derived cout block (see below)
   int Cin, H, W, Cout, kh, kw, ph, pw;   // conv consuming dy (B,Cin=Cout_orig,H=OH,W=OW), stride (sh,1)
   int sh, Hplan;                         // vertical stride V and the input height the planner must assume so that the
@@ -207,6 +208,12 @@ BwdDataGeom bwd_data_geom(const mpa_conv_desc* d) {
   } else if (d->sh == 1 && d->sw == d->kw && d->pw == 0 && OW * d->sw == d->W) {
     g.ok = true; g.xphase = true;       // non-overlapping windows along W: kw independent (kh x 1) convs
     g.Cout = d->kw * d->Cin; g.kh = d->kh; g.kw = 1; g.ph = d->kh - 1 - d->ph; g.pw = 0;
+  } else if (d->sh == d->kh && d->sw == d->kw && d->ph == 0 && d->pw == 0 && d->kh * d->kw <= 16) {
+    // non-overlapping windows in both directions (basic_cnn's conv2: 3x3, stride (3,3), basic_cnns.py:39): a 1x1 convolution
+    // to kh*kw*Cin phase channels, cout' = (cin*kh + v)*kw + q stored at (oy*kh + v, ox*kw + q); input rows / columns past
+    // the last full window get no gradient (the caller zero-fills dx when the windows do not tile the plane)
+    g.ok = true; g.xphase = true; g.xyphase = true;
+    g.Cout = d->kh * d->kw * d->Cin; g.kh = 1; g.kw = 1; g.ph = 0; g.pw = 0;
   } else {
     g.ok = false;
   }

@@ -1,14 +1,14 @@
 """Drop-in for ``libdl.nn_models`` (the reference's import surface, libdl/nn_models/__init__.py:1-10).
 
 The 7 model classes every experiment script instantiates, the 4 building
-blocks they are made of and 11 further variants the reference exports (8 U-Nets,
-``basic_cnn_pool`` and the two log-softmax CNNs: re-compositions of the same blocks) run on hand-written gfx950 kernels.  The
+blocks they are made of and 12 further variants the reference exports (8 U-Nets,
+``basic_cnn``, ``basic_cnn_pool`` and the two log-softmax CNNs: re-compositions of the same blocks) run on hand-written gfx950 kernels.  The
 remaining exported names (variants no experiment uses: the frequency U-Nets,
-the temporal transformer / BiLSTM variants, the strided basic_cnn -- two of
+the temporal transformer / BiLSTM variants -- two of
 them cannot even be constructed upstream) are kept
 importable and raise ``NotImplementedError`` on construction.
 """
-from .basic_cnns import (basic_cnn_pool, basic_cnn_segm_blank_logsoftmax, basic_cnn_segm_logsoftmax, basic_cnn_segm_sigmoid,
+from .basic_cnns import (basic_cnn, basic_cnn_pool, basic_cnn_segm_blank_logsoftmax, basic_cnn_segm_logsoftmax, basic_cnn_segm_sigmoid,
                          deep_cnn_segm_sigmoid)
 from .unet_cnns import (blstm_temporal_enc_layer, double_conv, simple_u_net, simple_u_net_doubleselfattn,
                         simple_u_net_doubleselfattn_alllayers, simple_u_net_doubleselfattn_polyphony,
@@ -25,9 +25,9 @@ BUILT = ["basic_cnn_segm_sigmoid", "deep_cnn_segm_sigmoid", "double_conv", "unet
          "simple_u_net", "simple_u_net_selfattn", "simple_u_net_sixselfattn", "simple_u_net_doubleselfattn_alllayers",
          "simple_u_net_doubleselfattn_varlayers", "simple_u_net_polyphony_classif",
          "simple_u_net_doubleselfattn_polyphony", "simple_u_net_doubleselfattn_polyphony_classif", "basic_cnn_pool",
-         "basic_cnn_segm_logsoftmax", "basic_cnn_segm_blank_logsoftmax"]
+         "basic_cnn_segm_logsoftmax", "basic_cnn_segm_blank_logsoftmax", "basic_cnn"]
 
-NOT_BUILT = ["basic_cnn", "single_conv", "freq_u_net", "freq_u_net_bottomstack",
+NOT_BUILT = ["single_conv", "freq_u_net", "freq_u_net_bottomstack",
              "freq_u_net_selfattn", "freq_u_net_doubleselfattn", "u_net_temporal_selfattn_varlayers",
              "transformer_temporal_enc_layer", "simple_u_net_doubleselfattn_transenc", "u_net_temporal_blstm_varlayers"]
 

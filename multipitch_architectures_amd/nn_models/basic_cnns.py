@@ -200,3 +200,44 @@ class basic_cnn_segm_blank_logsoftmax(nn.Module):
         # torch.cat((conv5b(.), conv5a(.)), dim=3) and the log-softmax over dim 1 in one kernel
         y_pred = self.logsoftmax7(self.conv5b(conv4_lrelu), self.conv5a(conv4_lrelu))
         return y_pred
+
+
+class basic_cnn(nn.Module):
+    """basic_cnns.py:5-65 -- Zeitler's basic CNN with strided convolutions: conv1 15x15 + pool (2,1); conv2 3x3 with stride
+    (3,3) + pool (2,1); conv3 (6,1); conv4 as everywhere.  HCQT (B,6,75,216) -> (B,1,1,n_bins_out).  No experiment script uses
+    it.  (The stride-(3,3) layer's backward-data runs as a 1x1 convolution to 9 phase channels: conv_plan.h: bwd_data_geom.)"""
+
+    def __init__(self, n_chan_input=6, n_chan_layers=[20, 20, 10, 1], n_bins_in=216, n_bins_out=12, a_lrelu=0.3,
+                 p_dropout=0.2):
+        super().__init__()
+        n_in, n_ch = n_chan_input, n_chan_layers
+        last_kernel_size = n_bins_in // 3 + 1 - n_bins_out
+        self.layernorm = LayerNorm(normalized_shape=[n_in, n_bins_in])
+        self.conv1 = ConvActPoolDrop(
+            Conv2d(n_in, n_ch[0], kernel_size=(15, 15), padding=(7, 7), stride=(1, 1)),
+            LeakyReLU(negative_slope=a_lrelu),
+            MaxPool2d(kernel_size=(2, 1), stride=(2, 1), padding=(0, 0)),
+            Dropout(p=p_dropout))
+        self.conv2 = ConvActPoolDrop(
+            Conv2d(n_ch[0], n_ch[1], kernel_size=(3, 3), padding=(0, 0), stride=(3, 3)),
+            LeakyReLU(negative_slope=a_lrelu),
+            MaxPool2d(kernel_size=(2, 1), stride=(2, 1), padding=(0, 0)),
+            Dropout(p=p_dropout))
+        self.conv3 = ConvActPoolDrop(
+            Conv2d(n_ch[1], n_ch[2], kernel_size=(6, 1), padding=(0, 0), stride=(1, 1)),
+            LeakyReLU(negative_slope=a_lrelu),
+            Dropout(p=p_dropout))
+        self.conv4 = OutputHead(
+            Conv2d(n_ch[2], n_ch[3], kernel_size=(1, 1), padding=(0, 0), stride=(1, 1)),
+            LeakyReLU(negative_slope=a_lrelu),
+            Dropout(p=p_dropout),
+            Conv2d(n_ch[3], 1, kernel_size=(1, last_kernel_size), padding=(0, 0), stride=(1, 1)),
+            Sigmoid())
+
+    def forward(self, x):
+        x_norm = self.layernorm.forward_cf(x)
+        conv1_lrelu = self.conv1(x_norm)
+        conv2_lrelu = self.conv2(conv1_lrelu)
+        conv3_lrelu = self.conv3(conv2_lrelu)
+        y_pred = self.conv4(conv3_lrelu)
+        return y_pred

@@ -793,3 +793,26 @@ def test_conv15_fold_switch(dev, monkeypatch):
     assert L.load().mpa_conv2d_fold_supported(ctypes.byref(d)) == 1
     monkeypatch.setenv("MPA_FOLD_OFF", "1")
     assert L.load().mpa_conv2d_fold_supported(ctypes.byref(d)) == 0
+
+
+@pytest.mark.parametrize("case", [(2, 8, 37, 216, 6, 3, 3), (2, 20, 37, 216, 20, 3, 3), (1, 16, 12, 30, 24, 3, 3), (2, 5, 9, 8, 7, 2, 4)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_conv2d_stride_equals_kernel(dev, case):
+    """non-overlapping windows in both directions (basic_cnn's conv2: 3x3 stride (3,3), basic_cnns.py:39): backward-data as a
+    1x1 convolution to kh*kw phase channels per input channel; rows / columns behind the last full window get zero gradient"""
+    from multipitch_architectures_amd import ops
+    B, Cin, H, W, Cout, kh, kw = case
+    x = _rand((B, Cin, H, W), 1)
+    w = _rand((Cout, Cin, kh, kw), 2, (2.0 / (Cin * kh * kw)) ** 0.5)
+    b = _rand((Cout,), 3, 0.1)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv2d(xr, wr, br, stride=(kh, kw))
+    gy = _rand(tuple(yr.shape), 4)
+    yr.backward(gy.double())
+    xg, wg, bg = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    y = ops.conv2d(xg, wg, bg, (kh, kw), (0, 0))
+    y.backward(gy.to(dev))
+    _close(y, yr, 2e-5, "y")
+    _close(xg.grad, xr.grad, 2e-5, "dx")
+    _close(wg.grad, wr.grad, 5e-5, "dw")
+    _close(bg.grad, br.grad, 5e-5, "db")
