@@ -25,6 +25,8 @@ namespace {
 
 __device__ __attribute__((aligned(16))) uint4 head_zero[64];
 
+
+
 __device__ __forceinline__ void hglds16(const void* src, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
@@ -99,7 +101,42 @@ __global__ __launch_bounds__(WM * WN * 64) void head_gemm_kernel(const HeadParam
               hlds + 2 * p.xslab + buf * p.AUw + (wave + n * NW) * 256);
   };
   // everything of a chunk at once
+  // MODE 0 / 1: what a piece moves does not depend on the chunk beyond a uniform channel offset, so the pieces go out as buffer
+  // loads to LDS -- per-lane byte offset from a table (a large offset for zeros: the resource's bounds check returns 0 for rows
+  // above / below the plane, pitch padding and channels past K), the chunk's offset on the scalar unit: ~3 instructions per
+  // piece instead of ~10 (measured: the staging burst costs the single wave of a SIMD its MFMA slots)
+  constexpr bool FAST = MODE != 2;
+  int vo[NSO];
+  if constexpr (FAST) {
+#pragma unroll
+    for (int n = 0; n < NSO; ++n) {
+      const int c = so[n] >> 16, q = SN * p0 - p.HALO + (so[n] & 0xffff);
+      vo[n] = (so[n] >= 0 && q >= 0 && q < p.SL) ? (c * p.SL + q) * 4 : 0x40000000;
+    }
+  }
+  const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)srcb, 0, (int)min((long)p.K * p.SL * 4, 0x3fffffffL), 0x00020000);
+  const auto arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)min((long)p.nChunks * p.AUw * 4, 0x3fffffffL), 0x00020000);
+  auto stage_fast = [&](int chunk, int buf) {
+    const int xso = chunk * p.CK * p.SL * 4, aso = chunk * p.AUw * 4;
+    if (!(p.dbg == 4 && chunk)) {
+#pragma unroll
+      for (int n = 0; n < NSO; ++n)
+        if (n < nxw)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(hlds + buf * p.xslab + (wave + n * NW) * 256),
+                                                   16, vo[n], xso, 0, 0);
+    }
+    if (!(p.dbg == 5 && chunk)) {
+#pragma unroll 1
+      for (int n = 0; n < naw; ++n)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (__attribute__((address_space(3))) void*)(hlds + 2 * p.xslab + buf * p.AUw + (wave + n * NW) * 256),
+                                                 16, ((wave + n * NW) * 64 + lane) * 16, aso, 0, 0);
+    }
+  };
   auto stage_from = [&](int n0, int chunk, int buf) {
+    if constexpr (FAST) {           // (head_params refuses tiles with more than NSO pieces per wave)
+      stage_fast(chunk, buf);
+      return;
+    }
     int cq = chunk, tg = 0;
     if (MODE == 2) { cq = chunk / p.NG; tg = chunk - cq * p.NG; }
     const int qg = SN * p0 - p.HALO + tg * p.grp_shift, kleft = p.K - cq * p.CK;
@@ -246,6 +283,7 @@ int head_params(const mpa_conv_desc* d, const HeadPlan& pl, HeadParams& p) {
   const int NW = pl.WM * pl.WN;
   const long instr = mpa_cdiv((long)pl.CK * (pl.XS / 4), 64);
   p.xinstr = (int)instr;
+  if (pl.mode < 2 && mpa_cdiv(instr, NW) > 12) return MPA_ERR_UNSUPPORTED;      // head_gemm_kernel: NSO table entries per wave
   p.xslab = (int)(instr * 256);      // the last instruction ends inside the buffer
   const int xu4 = pl.XS / 4;
   p.xmagic = (int)(((1L << 20) + xu4 - 1) / xu4);
