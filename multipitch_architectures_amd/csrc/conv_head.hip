@@ -224,6 +224,66 @@ __global__ __launch_bounds__(WM * WN * 64) void head_gemm_kernel(const HeadParam
 
   // lane (j, g) holds rows 4g .. 4g+3 of each 16-row tile at pixel column j of each pixel block
   float* ob = p.out + (long)b * p.outBS;
+  if constexpr (MODE == 1 && MT % 3 == 0) {
+    // backward-data: three 16-row tiles are 16 channels x 3 column phases, i.e. for a 16-pixel block 16 runs of 48 consecutive
+    // words of dx.  Transposed through a wave-private LDS patch they go out as 16-byte stores (30 per lane instead of 120
+    // scattered 4-byte ones: the scalar epilogue was ~10 % of the workgroup's life).
+    __syncthreads();                                  // the main loop's LDS images are dead now
+    float* patch = hlds + wave * (48 * 17);           // [row 48][pixel 16 (+1 pad)]
+#pragma unroll
+    for (int grp = 0; grp < MT / 3; ++grp) {
+      const int ci0 = ((wm * MT + 3 * grp) * 16) / 3;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int tl = 0; tl < 3; ++tl)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) patch[(tl * 16 + 4 * g + r) * 17 + j] = acc[3 * grp + tl][nb][r];
+        const int pxb = p0 + (wn * NB + nb) * 16;
+        const int nvalid = 3 * min(16, p.P - pxb);    // words of each run that exist (a multiple of 4)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int idx = lane + 64 * k, cl = idx / 12, f4 = idx - cl * 12;
+          float4 v;
+          float* e = reinterpret_cast<float*>(&v);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int wd = 4 * f4 + q, px = wd / 3, ph = wd - 3 * px;
+            e[q] = patch[(cl * 3 + ph) * 17 + px];
+          }
+          if (ci0 + cl < p.Mrows / 3 && 4 * f4 < nvalid)
+            *reinterpret_cast<float4*>(ob + (long)(ci0 + cl) * p.outPS + 3 * (long)pxb + 4 * f4) = v;
+        }
+      }
+    }
+    return;
+  }
+  if constexpr (FWD) {
+    // forward (and the tall filters): every 16 x 16 accumulator tile through a wave-private LDS patch so that a lane owns 4
+    // consecutive pixels of one output row and writes one 16-byte store (25-35 per lane instead of 100-140 4-byte ones)
+    __syncthreads();                                  // the main loop's LDS images are dead now
+    float* patch = hlds + wave * (16 * 20);           // [row 16][pixel 16 (+4 pad)]
+    const int rl = lane >> 2, quad = lane & 3;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int m = (wm * MT + t) * 16 + rl;
+      const float bs = (p.bias && m < p.Mrows) ? p.bias[m] : 0.f;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) patch[(4 * g + r) * 20 + j] = acc[t][nb][r];
+        const float4 v = *reinterpret_cast<const float4*>(patch + rl * 20 + 4 * quad);
+        const int px = p0 + (wn * NB + nb) * 16 + 4 * quad;
+        if (m < p.Mrows && px < p.P) {                // (P % 4 == 0: a quad is inside or outside as a whole)
+          float4 o;
+          o.x = mpa_apply_act(v.x + bs, p.act, p.slope); o.y = mpa_apply_act(v.y + bs, p.act, p.slope);
+          o.z = mpa_apply_act(v.z + bs, p.act, p.slope); o.w = mpa_apply_act(v.w + bs, p.act, p.slope);
+          *reinterpret_cast<float4*>(ob + (long)m * p.P + px) = o;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < MT; ++t)
 #pragma unroll
