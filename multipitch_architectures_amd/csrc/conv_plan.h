@@ -603,10 +603,11 @@ inline HeadPlan plan_head(const mpa_conv_desc* d, int mode) {
     if (tiles <= 7) { pl.WM = 1; pl.MT = tiles; }
     else { pl.WM = 2; pl.MT = (int)mpa_cdiv(tiles, 2); }
     pl.WN = 4;
-    // one workgroup per 320 pixels and all couts: below ~4 workgroups per CU the generic forward kernel (smaller tiles, cout
-    // tiles in the grid) fills the chip better -- measured (scratch/head_time.py, 128 -> 80): 73 against 84 TFLOP/s at batch
-    // 32, 88 against 80 at batch 64, 108 against 102 at batch 256.  Backward-data and backward-weight win at every batch.
-    long min_wgs = 1024;
+    // one workgroup per 320 pixels and all couts: below ~2 workgroups per CU the generic forward kernel (smaller tiles, cout
+    // tiles in the grid) fills the chip better -- measured (scratch/head_time.py, TFLOP/s head / generic): 128 -> 80 at batch 16
+    // 65 / 60, batch 32 83 / 84, batch 48 93 / 61, batch 256 113 / 102; 128 -> 200 at batch 16 60 / 66, batch 32 80 / 76.
+    // Backward-data and backward-weight win at every batch.
+    long min_wgs = 512;
     if (const char* e = getenv("MPA_HEAD_FWD_MIN_WGS")) min_wgs = atol(e);
     if ((long)d->B * mpa_cdiv(pl.P, 4 * pl.NB * 16) < min_wgs) return pl;
   } else {

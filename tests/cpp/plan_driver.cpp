@@ -56,6 +56,7 @@ int main() {
   one("conv2_80", 256, 128, 75, 216, 80, 3, 3, 1, 3, 1, 0);
   one("conv2_200", 256, 128, 75, 216, 200, 3, 3, 1, 3, 1, 0);
   one("conv2_80_b32", 32, 128, 75, 216, 80, 3, 3, 1, 3, 1, 0);
+  one("conv2_80_b16", 16, 128, 75, 216, 80, 3, 3, 1, 3, 1, 0);
   one("conv3_T174", 64, 80, 174, 72, 50, 75, 1, 1, 1, 0, 0);
   one("conv3_T75", 64, 80, 75, 72, 50, 75, 1, 1, 1, 0, 0);
   one("strided_unsupported", 4, 8, 20, 20, 8, 3, 3, 2, 2, 1, 1);

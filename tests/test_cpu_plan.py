@@ -66,7 +66,7 @@ def test_head_conv2_and_fold_plans(plans):
     assert w["S"] * w["chGroups"] * w["coGroups"] == 256                         # one workgroup per CU
     f2, w2 = plans[("conv2_200", "head0")], plans[("conv2_200", "headwg")]
     assert (f2["MT"], f2["WM"]) == (7, 2) and (w2["MT"], w2["coGroups"]) == (5, 3)
-    assert ("conv2_80_b32", "head0") not in plans                                # small launch: the generic forward kernel
+    assert ("conv2_80_b16", "head0") not in plans and ("conv2_80_b32", "head0") in plans   # small launch: the generic forward kernel
     assert plans[("conv2_80_b32", "headwg")]["NRB"] == 2                         # row blocks give 128 slices their items
     for k in ("foldf", "foldb"):
         p = plans[("prefilt", k)]

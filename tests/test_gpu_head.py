@@ -111,8 +111,8 @@ def test_head_conv_switch_off_gives_the_generic_kernels(dev, monkeypatch):
 
 def test_head_forward_goes_to_the_generic_kernel_for_small_launches(dev, monkeypatch):
     monkeypatch.delenv("MPA_HEAD_FWD_MIN_WGS")
-    assert _plan((32, 128, 75, 216, 80), 0).startswith("fwd<")             # 544 workgroups: the generic kernel fills the chip better
-    assert _plan((64, 128, 75, 216, 80), 0).startswith("head_gemm<5,1,4>")
+    assert _plan((16, 128, 75, 216, 80), 0).startswith("fwd<")             # 272 workgroups: the generic kernel fills the chip better
+    assert _plan((32, 128, 75, 216, 80), 0).startswith("head_gemm<5,1,4>")
     assert _plan((32, 128, 75, 216, 80), 1).startswith("head_gemm<6,4,2>")  # backward passes: at every batch
     assert _plan((32, 128, 75, 216, 80), 2).startswith("head_wgrad<5>")
 
