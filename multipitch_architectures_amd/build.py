@@ -13,7 +13,7 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libmpa_hip.so")
-SOURCES = ["conv_fwd.hip", "conv_wgrad.hip", "conv_wgrad15.hip", "conv_head.hip", "conv_bf16x3.hip", "norm.hip", "pool_up.hip", "pointwise.hip", "gemm.hip", "attn.hip", "data.hip", "metrics.hip", "annot.hip", "hcqt.hip"]
+SOURCES = ["conv_fwd_nb12.hip", "conv_fwd_nb45.hip", "conv_fwd_nb36.hip", "conv_fwd.hip", "conv_wgrad.hip", "conv_wgrad15.hip", "conv_head.hip", "conv_bf16x3.hip", "norm.hip", "pool_up.hip", "pointwise.hip", "gemm.hip", "attn.hip", "data.hip", "metrics.hip", "annot.hip", "hcqt.hip"]
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs.  Without it hipcc (ROCm 7.2) parks small accumulator
 # sets in VGPRs and round-trips them through a single AGPR tuple around every v_mfma (8 v_accvgpr moves + s_nop 9
 # per MFMA in conv_fwd_kernel<1,6>).
