@@ -16,6 +16,7 @@ resampling recursion -- and is checked against ``oracle/restate_hcqt.py``, a flo
 provided.
 """
 import ctypes
+from fractions import Fraction
 
 import numpy as np
 import torch
@@ -179,11 +180,27 @@ def _cqt_into(y, sr, hop, fmin, n_bins, bins_per_octave, out, members):
                                         len(members), _stream()), "mpa_cqt_mag_scatter")
 
 
+def _octave_classes(num_harmonics, num_subharmonics):
+    """The (sub)harmonics 1/(S+1) .. 1/2, 1 .. H (plane order of the HCQT tensor) grouped into classes of frequencies
+    that differ by whole octaves.  Per class: (lowest member as a float, [(octaves above it, plane index)]); the lowest
+    member's CQT, extended upwards by the largest shift, holds every member as a slice bins_per_octave * shift higher.
+    What hcqt.py:130-147 arrives at by searching the earlier harmonics for one a power of two below."""
+    ratios = [Fraction(1, s + 1) for s in range(num_subharmonics, 0, -1)] + [Fraction(h) for h in range(1, num_harmonics + 1)]
+    odd = lambda n: n // (n & -n)
+    classes = {}
+    for plane, r in enumerate(ratios):
+        classes.setdefault((odd(r.numerator), odd(r.denominator)), []).append((r, plane))
+    out = []
+    for members in classes.values():
+        lowest = min(r for r, _ in members)
+        out.append((float(lowest), [(int(r / lowest).bit_length() - 1, plane) for r, plane in members]))
+    return sorted(out)
+
+
 def efficient_hcqt_device(f_audio, fs=22050, fmin=NOTE_C1_HZ, fs_hcqt_target=91, bins_per_octave=60, num_octaves=6,
                           num_harmonics=5, num_subharmonics=1, center_bins=True, device=None, tuning=None):
     """compute_efficient_hcqt with the result left on the GPU: (float32 tensor (n_bins, n_frames, harmonics), fs_hcqt, hop)"""
     y = _as_device_audio(f_audio, device)
-    eps = np.finfo(float).eps
     num_octaves_eff = num_octaves + np.ceil(np.log2((num_subharmonics + 1)) + np.log2((num_harmonics))).astype(int)   # :112
     hopsize_cqt, fs_cqt = compute_hopsize_cqt(fs_hcqt_target, fs=fs, num_octaves=num_octaves_eff)
     fs_hcqt = fs / hopsize_cqt
@@ -196,33 +213,11 @@ def efficient_hcqt_device(f_audio, fs=22050, fmin=NOTE_C1_HZ, fs_hcqt_target=91,
     n_frames = np.floor(y.numel() / hopsize_cqt).astype(int) + 1
     n_bins = bins_per_octave * num_octaves
     f_hcqt = torch.zeros((n_bins, int(n_frames), num_harmonics + num_subharmonics), dtype=torch.float32, device=y.device)
-    # which harmonics share a CQT (hcqt.py:130-147, kept line by line)
-    list_harmonics = [1 / (n_sh + 1) for n_sh in range(num_subharmonics, 0, -1)] + [n_ha for n_ha in range(1, num_harmonics + 1)]
-    base_harmonics = np.zeros((len(list_harmonics)))
-    computed_harmonics = np.zeros((len(list_harmonics)))
-    base_harmonics[0] = 1 / (num_subharmonics + 1)
-    computed_harmonics[0] = 1
-    for n_h in range(1, len(list_harmonics)):
-        harmonic = list_harmonics[n_h]
-        n_base = 0
-        while computed_harmonics[n_h] < eps:
-            base = base_harmonics[n_base]
-            if base == 0:
-                base_harmonics[n_h] = list_harmonics[n_h]
-                computed_harmonics[n_h] = 1
-            elif np.mod(np.log2(harmonic / base), 1) == 0:
-                base_harmonics[n_h] = base
-                computed_harmonics[n_h] = 1
-            else:
-                n_base += 1
-    for base_h in np.unique(base_harmonics):
-        fmin_h = fmin_tuned * base_h
-        all_harmonics = np.where(base_harmonics == base_h)[0]
-        max_harmonic = np.max(all_harmonics)
-        num_add_octaves = int(np.ceil(np.log2(list_harmonics[max_harmonic] / base_h)))
-        n_bins_curr = (num_octaves + num_add_octaves) * bins_per_octave
-        members = [(int(np.log2(list_harmonics[h] / base_h).astype(int)) * bins_per_octave, int(h)) for h in all_harmonics]
-        _cqt_into(y, fs, hopsize_cqt, fmin_h, n_bins_curr, bins_per_octave, f_hcqt, members)
+    # harmonics whose frequencies are a whole number of octaves apart are slices of one CQT (hcqt.py:130-152)
+    for base_h, members in _octave_classes(num_harmonics, num_subharmonics):
+        n_bins_curr = (num_octaves + max(shift for shift, _ in members)) * bins_per_octave
+        _cqt_into(y, fs, hopsize_cqt, fmin_tuned * base_h, n_bins_curr, bins_per_octave, f_hcqt,
+                  [(shift * bins_per_octave, h) for shift, h in members])
     return f_hcqt, fs_hcqt, hopsize_cqt
 
 
