@@ -37,6 +37,11 @@ extern "C" {
 
 const char* mpa_strerror(int code);
 int mpa_version(void);
+/* Diagnostic switches (csrc/mpa_diag.h: MPA_FWD_FORCE, MPA_WG_VARIANT, MPA_HEAD_OFF ... -- tile / variant overrides for
+ * tests and timing scripts, none needed in production) are read from the environment once per process; a process that
+ * changes one of them afterwards calls this to read them again.  Returns 1 in a -DMPA_DIAG build (kernel-side debug
+ * switches compiled in), 0 in the release library. */
+int mpa_diag_reload(void);
 
 /* ------------------------------------------------------------------ convolution
  * Replaces nn.Conv2d in double_conv (unet_cnns.py:49-59), conv1/prefilt_list

@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401  -- must be imported BEFORE libmpa_hip.so is loaded: the library has to bind to the same
 #                        libamdhip64 that PyTorch brings, otherwise streams/pointers belong to another HIP runtime
 
-from .build import LIB, build_library
+from .build import DIAG_LIB, LIB, build_library
 
 c_void_p, c_int, c_int64, c_float, c_double, c_uint64 = (
     ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_uint64)
@@ -46,6 +46,7 @@ _D = ctypes.POINTER(ConvDesc)
 SIGNATURES = {
     "mpa_strerror": (ctypes.c_char_p, [c_int]),
     "mpa_version": (c_int, []),
+    "mpa_diag_reload": (c_int, []),
     "mpa_conv2d_packed_floats": (c_int64, [_D, c_int]),
     "mpa_conv2d_pack": (c_int, [_D, c_int, _P, _P, _P]),
     "mpa_conv2d_pack_entry_bytes": (c_int, []),
@@ -142,9 +143,10 @@ def load(build_if_missing: bool = False):
     global _lib
     if _lib is not None:
         return _lib
-    path = LIB
+    diag = os.environ.get("MPA_DIAG_LIB", "0") == "1"      # scratch/ timing experiments: the -DMPA_DIAG build
+    path = DIAG_LIB if diag else LIB
     if build_if_missing:
-        path = build_library()          # no-op when the in-tree .so matches the sources' digest
+        path = build_library(diag=diag)          # no-op when the in-tree .so matches the sources' digest
     if not os.path.exists(path):
         if True:
             raise RuntimeError(

@@ -38,18 +38,25 @@ def _digest():
     return h.hexdigest()
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    stamp = LIB + ".stamp"
-    digest = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == digest:
-        return LIB
+DIAG_LIB = os.path.join(CSRC, "libmpa_hip_diag.so")
+
+
+def build_library(force: bool = False, verbose: bool = False, diag: bool = False) -> str:
+    """diag=True: the -DMPA_DIAG build (kernel-side debug switches of csrc/mpa_diag.h compiled in) as libmpa_hip_diag.so,
+    for the timing experiments under scratch/ -- never what the package loads by default."""
+    lib = DIAG_LIB if diag else LIB
+    flags = FLAGS + (["-DMPA_DIAG"] if diag else [])
+    stamp = lib + ".stamp"
+    digest = _digest() + ("-diag" if diag else "")
+    if not force and os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read() == digest:
+        return lib
     hipcc = _hipcc()
-    objdir = os.path.join(CSRC, "build")
+    objdir = os.path.join(CSRC, "build_diag" if diag else "build")
     os.makedirs(objdir, exist_ok=True)
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
@@ -59,14 +66,15 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs],
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs],
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
     with open(stamp, "w") as f:
         f.write(digest)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build_library(force=True, verbose=True))
+    import sys
+    print(build_library(force=True, verbose=True, diag="--diag" in sys.argv))

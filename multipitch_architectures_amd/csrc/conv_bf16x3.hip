@@ -190,9 +190,9 @@ __global__ __launch_bounds__(512) void conv_bfx_kernel(const BfxParams p) {
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                         // every wave holds the slab in registers: its buffer is free
-      if (s + 1 < nslab && p.dbg < 2) stage_a(s + 1);       // ... and the next slab streams in behind the MFMAs
+      if (s + 1 < nslab && MPA_DBG(p) < 2) stage_a(s + 1);       // ... and the next slab streams in behind the MFMAs
       const uint4* xb = lds_x + xlane + 4 * q;
-      if (p.dbg == 3) continue;
+      if (MPA_DBG(p) == 3) continue;
       // input row d+1 is requested before the MFMAs of row d are issued: its LDS latency hides behind them
       bf16x8 bh = __builtin_bit_cast(bf16x8, xb[0]);
       bf16x8 bl = __builtin_bit_cast(bf16x8, xb[BFX_PX]);
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(512) void conv_bfx_kernel(const BfxParams p) {
     }
     if (chunk + 1 < p.C8) {
       __builtin_amdgcn_s_barrier();                         // every wave is done with this chunk's input tile
-      if (p.dbg < 1) stage_x(chunk + 1);
+      if (MPA_DBG(p) < 1) stage_x(chunk + 1);
     }
   }
 
@@ -278,7 +278,7 @@ BfxPlan bfx_plan(int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw
   if ((kh != 15 && kh != 9) || kw < 1 || kw > 16 || sh != 1 || sw != 1) return pl;
   const int OH = H + 2 * ph - kh + 1, OW = W + 2 * pw - kw + 1;
   if (OH <= 0 || OW <= 0) return pl;
-  static const int forceR = getenv("MPA_BFX_R") ? atoi(getenv("MPA_BFX_R")) : 0;      // diagnostics
+  const int forceR = mpa_diag().bfx_r;      // diagnostics
   // rows per wave: the candidate with the least padded rows (ties: the taller one, fewer filter-fragment reloads)
   const int cand15[2] = {15, 13}, cand9[3] = {19, 18, 13};
   const int* cand = kh == 15 ? cand15 : cand9;
@@ -330,7 +330,7 @@ int bfx_launch(const BfxGeom& g, int B, const void* xs, const void* wp, const fl
   p.QN = pl.QN; p.ph = g.ph; p.pw = g.pw;
   p.tilesY = pl.tilesY; p.tilesX = pl.tilesX; p.coTiles = pl.coTiles; p.nTilesAll = B * pl.tilesY * pl.tilesX;
   p.NW = pl.NW; p.act = act; p.slope = slope;
-  { const char* e = getenv("MPA_BFX_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+  p.dbg = mpa_diag().dbg_bfx;
   const dim3 grid((unsigned)(mpa_cdiv(p.nTilesAll, 8) * 8 * pl.coTiles));
   static bool attr = false;
   if (!attr) {
@@ -562,7 +562,7 @@ BfxWgPlan bfx_wg_plan(const mpa_conv_desc* d) {
   pl.coBlocks = (int)mpa_cdiv(d->Cout, 16);
   pl.ciBlocks = (int)mpa_cdiv(d->Cin, 16);
   const int groups = pl.coBlocks * pl.ciBlocks;
-  static const int forceS = getenv("MPA_BFX_WG_S") ? atoi(getenv("MPA_BFX_WG_S")) : 0;      // diagnostics
+  const int forceS = mpa_diag().bfx_wg_s;      // diagnostics
   int S = std::max(1, std::min(pl.strips, 256 / std::max(1, groups)));
   S = (int)mpa_cdiv(pl.strips, mpa_cdiv(pl.strips, S));                   // equal strips per slice
   if (forceS >= 1 && forceS <= pl.strips) S = forceS;

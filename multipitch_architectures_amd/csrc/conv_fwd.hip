@@ -313,7 +313,7 @@ static int conv_fwd_impl(int B, int Cin, int H, int W, int Cout, int kh, int kw,
   p.IN64 = (int)(mpa_cdiv((long)pl.CK * pl.CHP, 64) * 64);
   p.SL64 = (int)(mpa_cdiv((long)(pl.KWS ? pl.KWP : kw) * pl.CK * pl.COTP, 64) * 64);
   p.quad = pl.quad;
-  { const char* e = getenv("MPA_DEBUG_FWD"); p.dbg = e ? atoi(e) : 0; }
+  p.dbg = mpa_diag().dbg_fwd;
   p.act = act; p.slope = slope;
   p.outBS = outBS; p.outCS = outCS; p.outRS = outRS; p.outXmul = outXmul; p.outCdiv = outCdiv;
   p.outYmul = outYmul; p.outH = outH ? outH : pl.OH;

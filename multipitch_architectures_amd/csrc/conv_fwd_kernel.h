@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
   const int c_begin = blockIdx.z * p.chunksPer, c_end = min(p.nChunks, c_begin + p.chunksPer);
   for (int c = c_begin; c < c_end; ++c) {
     __syncthreads();   // every wave is done with the previous chunk's tile and slabs
-    const bool do_stage = (p.dbg != 1 && p.dbg != 3) || c == c_begin;
+    const bool do_stage = (MPA_DBG(p) != 1 && MPA_DBG(p) != 3) || c == c_begin;
     if (do_stage) {
       if (p.quad) {
         glds_stage_x16<EF>(lds_in, xb, lane, wave, p.CK, p.IH, p.LW, p.CHP, p.IN64, c * p.CK, iy0, x0a, p.Cin, p.H, p.W);
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
       if constexpr (KW > 0) {
         // kw = 15 always runs with 4-channel chunks (plan_fwd), so the channel-group loop has a single trip there
         const int nj = KW == 15 ? 1 : p.CK / 4;
-        if (p.dbg != 2)
+        if (MPA_DBG(p) != 2)
         for (int j = 0; j < nj; ++j) {
           const float* aw = lds_w + (KW == 15 ? 0 : j * 4 * p.COTP * KWP);
           const float* bp = lds_in + (KW == 15 ? 0 : j * 4 * p.CHP) + dy * p.LW;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
           }
         }
       } else
-      if (p.dbg != 2)
+      if (MPA_DBG(p) != 2)
       for (int j = 0; j < p.CK / 4; ++j) {
         const float* ap = lds_w + j * 4 * p.COTP + aoff;
         const float* bp = lds_in + j * 4 * p.CHP + dy * p.LW;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
               acc[nb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nb], bv[pb], acc[nb][pb], 0, 0, 0);
         }
       }
-      if (dy + 1 < p.kh && p.dbg != 3) {
+      if (dy + 1 < p.kh && MPA_DBG(p) != 3) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next slab has landed
         __syncthreads();                                   // ... and everyone is done reading this one
       }

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(WM * WN * 64) void head_gemm_kernel(const HeadParam
   const int nxw = (p.xinstr + NW - 1 - wave) / NW, naw = ((p.AUw >> 8) + NW - 1 - wave) / NW;   // pieces of this wave
   // (qg: plane word of the slab's first word for this chunk's tap group; sc: the chunk's first channel; kleft: channels left)
   auto xpiece = [&](int n, int off, int chunk, int buf, int qg, const float* sc, int kleft) {
-    if (n < nxw && !(p.dbg == 4 && chunk)) {
+    if (n < nxw && !(MPA_DBG(p) == 4 && chunk)) {
       const int c = off >> 16, q = qg + (off & 0xffff);
       // channels past K (last chunk) and words outside the plane (rows above / below it) are zeros
       const bool ok = off >= 0 && c < kleft && q >= 0 && q < p.SL;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(WM * WN * 64) void head_gemm_kernel(const HeadParam
     }
   };
   auto apiece = [&](int n, int chunk, int buf) {
-    if (n < naw && !(p.dbg == 5 && chunk))
+    if (n < naw && !(MPA_DBG(p) == 5 && chunk))
       hglds16(reinterpret_cast<const uint4*>(p.wp) + (long)chunk * (p.AUw >> 2) + (wave + n * NW) * 64 + lane,
               hlds + 2 * p.xslab + buf * p.AUw + (wave + n * NW) * 256);
   };
@@ -118,14 +118,14 @@ __global__ __launch_bounds__(WM * WN * 64) void head_gemm_kernel(const HeadParam
   const auto arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)min((long)p.nChunks * p.AUw * 4, 0x3fffffffL), 0x00020000);
   auto stage_fast = [&](int chunk, int buf) {
     const int xso = chunk * p.CK * p.SL * 4, aso = chunk * p.AUw * 4;
-    if (!(p.dbg == 4 && chunk)) {
+    if (!(MPA_DBG(p) == 4 && chunk)) {
 #pragma unroll
       for (int n = 0; n < NSO; ++n)
         if (n < nxw)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(hlds + buf * p.xslab + (wave + n * NW) * 256),
                                                    16, vo[n], xso, 0, 0);
     }
-    if (!(p.dbg == 5 && chunk)) {
+    if (!(MPA_DBG(p) == 5 && chunk)) {
 #pragma unroll 1
       for (int n = 0; n < naw; ++n)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (__attribute__((address_space(3))) void*)(hlds + 2 * p.xslab + buf * p.AUw + (wave + n * NW) * 256),
@@ -176,10 +176,10 @@ __global__ __launch_bounds__(WM * WN * 64) void head_gemm_kernel(const HeadParam
     const int buf = ci & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();              // this chunk has landed everywhere; nobody still reads the other buffer
-    const bool more = ci + 1 < nch && p.dbg < 2;
-    if (p.dbg == 3 || !INTER) {
+    const bool more = ci + 1 < nch && MPA_DBG(p) < 2;
+    if (MPA_DBG(p) == 3 || !INTER) {
       if (more) stage_from(0, real(ci + 1), buf ^ 1);
-      if (p.dbg == 3) continue;
+      if (MPA_DBG(p) == 3) continue;
     }
     const float* xb = hlds + buf * p.xslab + g * p.XS + SN * (wn * NB * 16 + j);
     const float* ab = hlds + 2 * p.xslab + buf * p.AUw + wm * MT * 64 + lane;
@@ -351,7 +351,7 @@ int head_params(const mpa_conv_desc* d, const HeadPlan& pl, HeadParams& p) {
     if ((int)(((unsigned long)u * (unsigned long)p.xmagic) >> 20) != (int)(u / xu4) || u * (long)p.xmagic >= (1L << 32))
       return MPA_ERR_UNSUPPORTED;
   p.AUw = (int)pl.AUw;
-  { const char* e = getenv("MPA_HEAD_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+  p.dbg = mpa_diag().dbg_head;
   for (int t = 0; t < 25; ++t) p.tapoff[t] = 0;
   p.NG = 1; p.grp_shift = 0;
   if (pl.mode == 0) {
@@ -515,17 +515,17 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const HeadWgParams p) {
       const int s0 = i % 3, s1 = (i + 1) % 3, s2 = (i + 2) % 3, dbuf = i & 1;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();             // input row h + 1 and dY row h have landed
-      if (p.dbg != 3) taps(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, false, s0, dbuf, 0, 0, 0, 0);
+      if (MPA_DBG(p) != 3) taps(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, false, s0, dbuf, 0, 0, 0, 0);
       __builtin_amdgcn_s_barrier();             // everyone is done with input row h - 1: its slot takes row h + 2 ...
-      const bool more = h + 1 < r1 && p.dbg < 2;
-      if (p.dbg != 3) {                         // ... piece by piece behind the MFMAs of the other two filter rows
+      const bool more = h + 1 < r1 && MPA_DBG(p) < 2;
+      if (MPA_DBG(p) != 3) {                         // ... piece by piece behind the MFMAs of the other two filter rows
         taps(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, more, s1, dbuf, h + 2, s0, h + 1, dbuf ^ 1);
         taps(std::integral_constant<int, 2>{}, std::integral_constant<int, KSC>{}, more, s2, dbuf, h + 2, s0, h + 1, dbuf ^ 1);
       }
       if (more) {
 #pragma unroll
         for (int n = 0; n < HEAD_WG_NX + HEAD_WG_ND; ++n)
-          if (n >= 2 * KSC || p.dbg == 3) piece(n, h + 2, s0, h + 1, dbuf ^ 1);
+          if (n >= 2 * KSC || MPA_DBG(p) == 3) piece(n, h + 2, s0, h + 1, dbuf ^ 1);
       }
     }
   }
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const HeadWgParams p) {
 
 template <int MT>
 int head_wgrad_launch(const HeadWgPlan& pl, const HeadWgParams& p, hipStream_t s) {
-  auto k = (p.KS == 9 && !getenv("MPA_HEAD_WG_ROLLED")) ? head_wgrad_kernel<MT, 9> : head_wgrad_kernel<MT, 0>;
+  auto k = (p.KS == 9 && !mpa_diag().head_wg_rolled) ? head_wgrad_kernel<MT, 9> : head_wgrad_kernel<MT, 0>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)head_wgrad_kernel<MT, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
@@ -642,7 +642,7 @@ int mpa_conv_head_bwd_weight(const mpa_conv_desc* d, const float* x, const float
     if (u < pl.XUs && (int)((u * p.xmagic) >> 20) != (int)(u / pl.XPu)) return MPA_ERR_UNSUPPORTED;
     if (u < pl.DUs && (int)((u * p.dmagic) >> 20) != (int)(u / pl.DPu)) return MPA_ERR_UNSUPPORTED;
   }
-  { const char* e = getenv("MPA_HEAD_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+  p.dbg = mpa_diag().dbg_head;
   int rc;
   switch (pl.MT) {
     case 1: rc = head_wgrad_launch<1>(pl, p, s); break;

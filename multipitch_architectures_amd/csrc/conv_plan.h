@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include "../../include/mpa.h"
+#include "mpa_diag.h"
 
 namespace {
 
@@ -62,9 +63,8 @@ FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
   // resident slots costs 5 rounds, not 4.1)
   const int nbs[6] = {1, 2, 4, 5, 3, 6};
   const int pbs[6] = {1, 2, 4, 6, 8, 12};
-  static const char* force = getenv("MPA_FWD_FORCE");          // diagnostics: "NB,PB" restricts the search
-  int fNB = 0, fPB = 0;
-  if (force) sscanf(force, "%d,%d", &fNB, &fPB);
+  const MpaDiag& diag = mpa_diag();          // diagnostics (mpa_diag.h): fwd_nb, fwd_pb restrict the search
+  const int fNB = diag.fwd_nb, fPB = diag.fwd_pb;
   for (int ni = 0; ni < 6; ++ni) {
     const int NB = nbs[ni];
     if (fNB && NB != fNB) continue;
@@ -144,8 +144,7 @@ FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
             // zeroed output.  Each extra slice pays a prologue/epilogue (~6 % of a full-K workgroup).
             const int nChunks = (int)mpa_cdiv(Cin, CK);
             int KS = 1;
-            static const int ks_max = getenv("MPA_FWD_KS_MAX") ? atoi(getenv("MPA_FWD_KS_MAX")) : 16;   // diagnostics
-            static const int ks_force = getenv("MPA_FWD_KS_FORCE") ? atoi(getenv("MPA_FWD_KS_FORCE")) : 0;   // diagnostics
+            const int ks_max = diag.fwd_ks_max, ks_force = diag.fwd_ks_force;   // diagnostics
             if (ks_force > 1 && allow_split && ks_force <= nChunks) KS = ks_force;
             else
             if (xcu <= 2.0 * bpc && allow_split) {
@@ -241,7 +240,7 @@ struct FoldPlan {
 inline FoldPlan plan_fold(int Cout_out, int kh, int kw, int sh, int sw, int H) {
   FoldPlan f{};
   f.ok = false;
-  if (kh != 15 || kw != 15 || sh != 1 || sw != 1 || getenv("MPA_FOLD_OFF")) return f;
+  if (kh != 15 || kw != 15 || sh != 1 || sw != 1 || mpa_diag().fold_off) return f;
   f.R = Cout_out % 16;
   f.C0 = Cout_out - f.R;
   if (f.R < 1 || f.R > 8 || f.C0 < 16) return f;
@@ -274,9 +273,9 @@ WgPlan plan_wgrad(const mpa_conv_desc* d) {
   // wave tile variants (cout blocks x tap blocks); many tap blocks per wave = few dY floats staged per MFMA
   const int var_nbc[5] = {1, 2, 2, 4, 5}, var_ntw[5] = {16, 8, 16, 6, 6};
   double bestcost = 1e300;
-  const char* var_env = getenv("MPA_WG_VARIANT");        // diagnostics / tests: restrict the search to one wave tile
+  const MpaDiag& diag = mpa_diag();        // diagnostics / tests: wg_variant restricts the search to one wave tile
   for (int v = 0; v < 5; ++v) {
-    if (var_env && atoi(var_env) != v) continue;
+    if (diag.wg_variant >= 0 && diag.wg_variant != v) continue;
     WgPlan pl{};
     pl.OH = OH; pl.OW = OW; pl.Ntot = Ntot;
     pl.NBC = var_nbc[v]; pl.NTW = var_ntw[v];
@@ -288,13 +287,12 @@ WgPlan plan_wgrad(const mpa_conv_desc* d) {
     // cost of a variant = cost of one (pixel tile, block) x the number of (cout tile, tap tile) blocks that have to visit
     // every pixel tile.  (Round 1 multiplied by the padding ratio only, which compared the *per-block* cost of variants
     // whose blocks cover different amounts of work: for 128->200 3x3 it picked 7 x 3 blocks of <2,8> over 3 x 3 of <5,6>.)
-    static const bool old_norm = getenv("MPA_WG_COSTNORM") && atoi(getenv("MPA_WG_COSTNORM")) == 0;   // diagnostics
+    const bool old_norm = diag.wg_costnorm_old;   // diagnostics
     const double pad_eff = old_norm ? ((double)pl.coTiles * pl.COT / d->Cout) * ((double)pl.nTiles * pl.nPerBlock / Ntot)
                                     : (double)pl.coTiles * pl.nTiles / 8.0;
-    static const int force_txn = getenv("MPA_WG_TXN") ? atoi(getenv("MPA_WG_TXN")) : 0;   // diagnostics
+    const int force_txn = diag.wg_txn;   // diagnostics
     // dY-from-global variant: exact tiling of 4-aligned rows, stride 1 (any variant) or the head's stride 3 (<5,6>)
-    const char* ga_env = getenv("MPA_WG_GA");            // diagnostics / tests: "0" = never, "force" = whenever feasible
-    const bool no_ga = ga_env && ga_env[0] == '0', force_ga = ga_env && ga_env[0] == 'f';
+    const bool no_ga = diag.wg_no_ga, force_ga = diag.wg_force_ga;   // diagnostics / tests: MPA_WG_GA = "0" never, "force" whenever feasible
     bool ga_found = false;
     const bool ga_sw = d->sw == 1 || (d->sw == 3 && pl.NBC == 5);
     const bool ga_ef = (OW & 3) || (d->W & 3);      // unaligned rows: one tile per row, <2,8> only, stride 1
@@ -392,7 +390,7 @@ WgPlan plan_wgrad(const mpa_conv_desc* d) {
   // few tiles per slice: pick the slice count by the same small model as plan_wgrad15 (the busiest CU's workgroups x
   // tiles per slice x tile time, + 8 % when a CU holds a single workgroup, + one write and read of the partial sums
   // per slice) -- 160 tiles over 93 slices are 2 tiles for most workgroups and 1 for the rest
-  if (totalTiles / S < 8 && !getenv("MPA_WG_S_OLD")) {
+  if (totalTiles / S < 8 && !diag.wg_s_old) {
     const long lo = std::max<long>(1, S / 2), hi = std::min<long>(std::min<long>(2 * S, totalTiles), 1024);
     const double t_tile = 1.1 * (double)best.TH * (best.DP / 4) * best.NBC * best.NTW * 32.0 / 2.4e9;
     const double t_slice = (double)std::min(d->Cout, best.COT * best.coTiles) * (best.Ntot + 1) * 8.0 / 4.0e12;
@@ -406,8 +404,8 @@ WgPlan plan_wgrad(const mpa_conv_desc* d) {
     }
     S = bestS;
   }
-  if (const char* e = getenv("MPA_WG_S")) {      // diagnostics: force the slice count
-    const long f = atol(e);
+  if (diag.wg_s) {      // diagnostics: force the slice count
+    const long f = diag.wg_s;
     if (f >= 1 && f <= std::min<long>(totalTiles, 1024)) S = f;
   }
   best.S = (int)S;
@@ -447,7 +445,7 @@ Wg15Plan plan_wgrad15(const mpa_conv_desc* d) {
   const long budget = 78 * 1024;      // two workgroups per CU (160 KiB LDS)
   double bestcost = 1e300;
   // dY-from-global variant: whole-width quads, at most 7 groups of 16 pixels per row (X pitch 128)
-  if (OW % 4 == 0 && !getenv("MPA_WG15_LDS_DY")) {
+  if (OW % 4 == 0 && !mpa_diag().wg15_lds_dy) {
     for (int txn = 1; txn <= 8; ++txn) {
       const int TW = (int)mpa_cdiv(mpa_cdiv(OW, txn), 4) * 4;
       if (TW > 112 || TW < 16 || (long)TW * txn != OW) continue;      // exact tiling: no per-lane column bounds
@@ -501,7 +499,7 @@ Wg15Plan plan_wgrad15(const mpa_conv_desc* d) {
   // 9..24 couts are left (16 instead of 32 rows of MFMA work for a half-filled tile); and whatever is then left, at
   // most 8 couts, tap-folded (70 = 2 x 32 + fold 6 for DRCNN:L's prefilters, 20 = 16 + fold 4, 40 = 32 + fold 8).
   pl.n32 = pl.coTiles; pl.has16 = 0; pl.fold_R = 0;
-  if (pl.ga && !getenv("MPA_WG15_NOFOLD")) {
+  if (pl.ga && !mpa_diag().wg15_nofold) {
     pl.n32 = d->Cout / 32;
     int rem = d->Cout - 32 * pl.n32;
     if (rem > 24) { pl.n32 += 1; rem = 0; }
@@ -539,7 +537,7 @@ Wg15Plan plan_wgrad15(const mpa_conv_desc* d) {
   // + 8 % when a CU holds a single workgroup and nothing overlaps its staging), and every slice costs one write and one
   // read of its partial sums in the reduction (0.9 us for 128 couts x 16 channels, which is why the large layers want
   // few slices and the 16-cout layers many).
-  if (totalTiles / S < 8 && !getenv("MPA_WG15_S_OLD")) {
+  if (totalTiles / S < 8 && !mpa_diag().wg15_s_old) {
     const long lo = std::max<long>(1, S / 2), hi = std::min<long>(std::min<long>(2 * S, totalTiles), 1024);
     const double t_tile = 1.1 * (double)pl.TH * (pl.TW / 4) * pl.NBC * 15 * 32.0 / 2.4e9;
     const double t_slice = (double)d->Cout * (d->Cin * 225 + 1) * 8.0 / 4.0e12;
@@ -553,8 +551,8 @@ Wg15Plan plan_wgrad15(const mpa_conv_desc* d) {
     }
     S = bestS;
   }
-  if (const char* e = getenv("MPA_WG15_S")) {      // diagnostics: force the slice count
-    const long f = atol(e);
+  if (mpa_diag().wg15_s) {      // diagnostics: force the slice count
+    const long f = mpa_diag().wg15_s;
     if (f >= 1 && f <= std::min<long>(totalTiles, 1024)) S = f;
   }
   pl.S = (int)S;
@@ -585,7 +583,7 @@ struct HeadPlan {
 
 inline bool head_geom_ok(const mpa_conv_desc* d) {
   return d->kh == 3 && d->kw == 3 && d->sh == 1 && d->sw == 3 && d->ph == 1 && d->pw == 0 && d->W % 12 == 0 && d->W >= 12 &&
-         d->H >= 1 && ((long)d->H * d->W) % 4 == 0 && !getenv("MPA_HEAD_OFF");
+         d->H >= 1 && ((long)d->H * d->W) % 4 == 0 && !mpa_diag().head_off;
 }
 
 inline HeadPlan plan_head(const mpa_conv_desc* d, int mode) {
@@ -608,7 +606,7 @@ inline HeadPlan plan_head(const mpa_conv_desc* d, int mode) {
     // 65 / 60, batch 32 83 / 84, batch 48 93 / 61, batch 256 113 / 102; 128 -> 200 at batch 16 60 / 66, batch 32 80 / 76.
     // Backward-data and backward-weight win at every batch.
     long min_wgs = 512;
-    if (const char* e = getenv("MPA_HEAD_FWD_MIN_WGS")) min_wgs = atol(e);
+    if (mpa_diag().head_fwd_min_wgs >= 0) min_wgs = mpa_diag().head_fwd_min_wgs;
     if ((long)d->B * mpa_cdiv(pl.P, 4 * pl.NB * 16) < min_wgs) return pl;
   } else {
     pl.K = d->Cout; pl.Mrows = 3 * d->Cin; pl.NT = 3; pl.SN = 1; pl.HALO = OW; pl.SL = d->H * OW;
@@ -630,8 +628,7 @@ inline HeadPlan plan_head(const mpa_conv_desc* d, int mode) {
     pl.lds_bytes = 2 * ((size_t)mpa_cdiv((long)ck * (pl.XS / 4), 64) * 256 + (size_t)pl.AUw) * 4;
     return pl.lds_bytes;
   };
-  int ck = 0;
-  if (const char* e = getenv("MPA_HEAD_CK")) ck = atoi(e) == 4 ? 4 : 8;
+  int ck = mpa_diag().head_ck;
   if (!ck) ck = (pl.WM * pl.WN == 4 && lds_of(4) <= 78 * 1024) ? 4 : 8;
   if (lds_of(ck) > 150 * 1024) {
     if (ck == 8 && lds_of(4) <= 150 * 1024) ck = 4;
@@ -656,7 +653,7 @@ inline HeadPlan plan_tall(const mpa_conv_desc* d, int mode, int* NGout = nullptr
   pl.ok = false;
   const int OH = d->H - d->kh + 1;
   if (d->kw != 1 || d->sh != 1 || d->sw != 1 || d->ph != 0 || d->pw != 0 || d->kh < 30 || OH < 2 || d->W % 4 || d->Cin < 16 ||
-      d->Cout < 16 || getenv("MPA_TALL_OFF"))
+      d->Cout < 16 || mpa_diag().tall_off)
     return pl;
   const int rows = mode == 2 ? d->Cout : d->Cin;
   const int tiles = (int)mpa_cdiv(rows, 16);
@@ -742,7 +739,7 @@ inline HeadWgPlan plan_head_wgrad(const mpa_conv_desc* d) {
   pl.NRB = (int)mpa_cdiv(d->H, pl.RB);
   pl.items = (long)d->B * pl.NCS * pl.NRB;
   long S = std::min<long>(pl.items, want);
-  if (const char* e = getenv("MPA_HEAD_WG_S")) { const long f = atol(e); if (f >= 1 && f <= pl.items) S = f; }
+  if (const long f = mpa_diag().head_wg_s) { if (f >= 1 && f <= pl.items) S = f; }
   pl.itemsPer = mpa_cdiv(pl.items, S);
   pl.S = (int)mpa_cdiv(pl.items, pl.itemsPer);
   pl.ok = true;

@@ -58,8 +58,8 @@ __global__ __launch_bounds__(256) void conv_wgrad15_kernel(const Wg15Params p) {
     const int tr = (int)(tile - (long)b * tilesPerImg);
     const int ty = tr / p.tilesX, tx = tr - ty * p.tilesX;
     const int oy0 = ty * p.TH, ox0 = tx * p.TW;
-    if (p.dbg != 3) __syncthreads();
-    if ((p.dbg != 1 && p.dbg != 3) || tile == split) {
+    if (MPA_DBG(p) != 3) __syncthreads();
+    if ((MPA_DBG(p) != 1 && MPA_DBG(p) != 3) || tile == split) {
       if (p.quad) {
         glds_stage_x16(lds_x, p.x + (long)b * p.Cin * p.H * p.W, lane, wave, 4 * CIW, p.IH, W15_PITCH, xchp, p.TX64,
                        ci_first, oy0 - 7, ox0 - 8, p.Cin, p.H, p.W);
@@ -73,8 +73,8 @@ __global__ __launch_bounds__(256) void conv_wgrad15_kernel(const Wg15Params p) {
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (p.dbg != 3 || tile == split) __syncthreads();
-    if (p.dbg == 2) continue;
+    if (MPA_DBG(p) != 3 || tile == split) __syncthreads();
+    if (MPA_DBG(p) == 2) continue;
     if (do_bias) {
       const int co = tid >> 1, part = tid & 1;
       if (co < p.COT) {
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad15g_kernel(const Wg15Params 
         a[cb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(dy_rsrc(cb, py, 16 * g, true), loff, 0, 0));
     };
     __syncthreads();
-    if (p.dbg != 1 || tile == split)
+    if (MPA_DBG(p) != 1 || tile == split)
       glds_stage_x16(lds_x, p.x + (long)b * p.Cin * p.H * p.W, lane, wave, 4, p.IH, W15_PITCH, xchp, p.TX64, ci_first,
                      oy0 - 7, ox0 - 8, p.Cin, p.H, p.W);
     float4 an[W15G_DEPTH][NBC];       // dY quads of the next W15G_DEPTH groups, in flight
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad15g_kernel(const Wg15Params 
     for (int d = 0; d < W15G_DEPTH; ++d) load_full(an[d], d / nfull, d % nfull);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (p.dbg == 2) continue;
+    if (MPA_DBG(p) == 2) continue;
 
     float b0[15], b1[15];
 #define W15G_LOAD(Bv, BP, IMM)                                                              \
@@ -527,7 +527,7 @@ int mpa_conv2d_bwd_weight(const mpa_conv_desc* d, const float* x, const float* d
     q.B = d->B; q.Cin = d->Cin; q.H = d->H; q.W = d->W; q.Cout = d->Cout; q.OH = d->H; q.OW = d->W;
     q.COT = p15.COT; q.TH = p15.TH; q.TW = p15.TW; q.DP = p15.DP; q.tilesY = p15.tilesY; q.tilesX = p15.tilesX;
     q.IH = p15.IH; q.IW = p15.IW; q.DCP = p15.DCP; q.S = p15.S; q.Ntot = Ntot; q.TX64 = p15.TX64; q.TD64 = p15.TD64; q.quad = p15.quad;
-    { const char* e = getenv("MPA_DEBUG_WG15"); q.dbg = e ? atoi(e) : 0; }
+    q.dbg = mpa_diag().dbg_wg15;
     hipStream_t s15 = (hipStream_t)stream;
     dim3 grid15((unsigned)p15.S, (unsigned)p15.ciGroups, (unsigned)p15.coTiles);
     static bool attr_set = false;

@@ -310,9 +310,9 @@ int gemm_impl(GemmParams p, int nbatch, int shared_c, hipStream_t s) {
       if (cost < best) { best = cost; variant = v; splits = sp; }
     }
   }
-  if (const char* e = getenv("MPA_GEMM_FORCE")) {            // diagnostics: "variant,splits"
-    int fv = -1, fs = 0;
-    if (sscanf(e, "%d,%d", &fv, &fs) == 2 && fv >= 0 && fv < 4 && fs >= 1 && fs <= 32 && (fs == 1 || act == MPA_ACT_NONE)) {
+  if (mpa_diag().gemm_variant >= 0) {            // diagnostics: MPA_GEMM_FORCE="variant,splits"
+    const int fv = mpa_diag().gemm_variant, fs = mpa_diag().gemm_splits;
+    if (fv >= 0 && fv < 4 && fs >= 1 && fs <= 32 && (fs == 1 || act == MPA_ACT_NONE)) {
       variant = fv; splits = fs;
     }
   }

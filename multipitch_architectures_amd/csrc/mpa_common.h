@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/mpa.h"
+#include "mpa_diag.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -609,6 +609,15 @@ const char* mpa_strerror(int code) {
   }
 }
 int mpa_version(void) { return 1; }
+
+int mpa_diag_reload(void) {
+  mpa_diag_mutable() = mpa_diag_read();
+#ifdef MPA_DIAG
+  return 1;
+#else
+  return 0;
+#endif
+}
 int mpa_logsoftmax_cat_fwd(const float* a, const float* b, float* y, int B, int C, int R, int Wa, int Wb, void* stream) {
   if (!a || !y || B <= 0 || C <= 0 || R <= 0 || Wa <= 0 || Wb < 0 || (Wb > 0 && !b)) return MPA_ERR_ARG;
   const long n = (long)B * R * (Wa + Wb);

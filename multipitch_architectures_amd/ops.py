@@ -271,7 +271,9 @@ def _packed_bfx(weight, desc, mode):
     sig = (weight.data_ptr(), weight._version, _param_epoch)
     ent = _bfx_cache.get(id(weight))
     if ent is None or ent[0]() is not weight or ent[1] != sig:
-        old = ent[2] if ent is not None and ent[0]() is weight else {}
+        # every bank this weight ever had stays alive (and in place) as long as the weight does: a captured graph packs
+        # into and reads the banks of *its* shapes, whichever banks the passes in between (evaluation: forward only) used
+        old = {**ent[3], **ent[2]} if ent is not None and ent[0]() is weight else {}
         ent = (weakref.ref(weight), sig, {}, old)
         _bfx_cache[id(weight)] = ent
         if len(_bfx_cache) > 1024:

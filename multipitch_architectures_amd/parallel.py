@@ -7,10 +7,18 @@ BatchNorm statistics and the batch-axis attention stay *local* to a rank (exactl
 ``DistributedDataParallel`` would do), gradients are averaged over ranks.
 
 Why buckets sized like this: xGMI is point-to-point (7 links x ~153 GB/s per GPU), a ring all-reduce of G bytes
-moves 2(N-1)/N * G per GPU over one link pair, i.e. ~0.4 ms for SAUnet:L's 32.5 MB -- against >100 ms of backward.
-A handful of large buckets (default 16 MB) keeps every collective bandwidth-bound rather than latency-bound, and
-since the decoder's gradients (the expensive 15x15 layers) are produced first, their bucket is on the wire while the
-encoder is still back-propagating.
+moves 2(N-1)/N * G per GPU over one link pair, i.e. ~0.4 ms for SAUnet:L's 32.5 MB -- against ~18 ms of backward at the
+local batch of an 8-GPU run.  A handful of large buckets (default 8 MB) keeps every collective bandwidth-bound rather
+than latency-bound, and since the head's and the decoder's gradients are produced first, their buckets are on the wire
+while the encoder is still back-propagating.  Only the last bucket cannot overlap anything, so it is kept small
+(`tail_bytes`, default 2 MB: the first encoder layers -- 1.7 MB for SAUnet:L).
+
+Two ways a step drives this class:
+* kernel by kernel (`finish()` after `loss.backward()`): the hooks put each bucket on the wire the moment its last
+  gradient has been accumulated;
+* `step.TrainStep` replaying the step as HIP graphs: the backward pass is captured as one graph *segment per bucket*
+  (the hook of a bucket's last gradient cuts the capture, `on_bucket`), and the replay launches bucket k's all-reduce
+  between segment k and segment k+1 -- same overlap, no collective inside a captured graph.
 """
 import torch
 import torch.distributed as dist
@@ -35,7 +43,7 @@ class GradientAverager:
         optimizer.step()
     """
 
-    def __init__(self, params, bucket_bytes: int = 16 << 20, process_group=None):
+    def __init__(self, params, bucket_bytes: int = 8 << 20, process_group=None, tail_bytes: int = 2 << 20):
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -45,17 +53,31 @@ class GradientAverager:
         # launch_all() -- what `step.TrainStep` sets while it captures forward + backward as a HIP graph (no collective
         # inside a captured graph; they run between the step's two graphs)
         self.deferred = False
+        # deferred mode: called with the bucket's index right after its gather (on autograd's device thread) -- where
+        # `step.TrainStep` cuts its capture
+        self.on_bucket = None
         # reverse registration order ~ order in which autograd produces gradients
-        cur, cur_bytes = [], 0
+        plists, cur, cur_bytes = [], [], 0
         for p in reversed(self.params):
             nbytes = p.numel() * p.element_size()
             if cur and cur_bytes + nbytes > bucket_bytes:
-                self._add_bucket(cur)
+                plists.append(cur)
                 cur, cur_bytes = [], 0
             cur.append(p)
             cur_bytes += nbytes
         if cur:
-            self._add_bucket(cur)
+            plists.append(cur)
+        # the last bucket is the one whose all-reduce nothing can hide: cap it at tail_bytes (the parameters registered
+        # first, i.e. whose gradients arrive last)
+        if plists and tail_bytes and tail_bytes < bucket_bytes:
+            last, tail, nb = plists[-1], [], 0
+            while len(last) > 1 and nb + last[-1].numel() * last[-1].element_size() <= tail_bytes:
+                nb += last[-1].numel() * last[-1].element_size()
+                tail.insert(0, last.pop())
+            if tail:
+                plists.append(tail)
+        for pl in plists:
+            self._add_bucket(pl)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
     def _add_bucket(self, plist):
@@ -70,7 +92,7 @@ class GradientAverager:
             offs.append(off)
             off += p.numel()
         b = {"params": plist, "flat": flat, "views": views, "pending": len(plist), "handle": None, "offsets": offs,
-             "gathered": False}
+             "gathered": False, "index": len(self.buckets)}
         for p in plist:
             self._owner[p] = b
         self.buckets.append(b)
@@ -83,7 +105,10 @@ class GradientAverager:
             # copy per parameter -- 168 of them for SAUnet:L) and put it on the wire
             self._gather(b)
             b["gathered"] = True
-            if self.world > 1 and not self.deferred:
+            if self.deferred:
+                if self.on_bucket is not None:
+                    self.on_bucket(b["index"])
+            elif self.world > 1:
                 b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     @staticmethod
@@ -119,6 +144,12 @@ class GradientAverager:
                         b["views"][i].zero_()
                 self._gather(b)
                 b["gathered"] = True
+
+    def launch(self, index):
+        """bucket `index` on the wire (asynchronous: the collective waits for what the current stream holds so far)"""
+        b = self.buckets[index]
+        if self.world > 1 and b["handle"] is None:
+            b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def launch_all(self):
         """one asynchronous all-reduce per bucket that is not on the wire yet"""

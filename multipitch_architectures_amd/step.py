@@ -16,13 +16,24 @@ running statistics), so one capture serves the whole run.
 
 Batches whose shape differs from the captured one (the last, smaller batch of an epoch) run eagerly.
 
-Data-parallel ranks (an ``averager``) replay the step as *two* graphs with the collectives between them: graph A =
-forward + loss + backward + the gather of every gradient bucket into its flat buffer, then the bucketed RCCL all-reduces
-launched from the host, then graph B = 1/world scale + AdamW + dropout-stream advance.  No collective sits inside a
-captured graph, and a rank issues 2 graph launches + a handful of collectives per step instead of ~480 kernel launches
--- which is what keeps eight ranks that share one host CPU off each other's critical path.  The all-reduce no longer
-overlaps the backward pass; for SAUnet:L that is 32.5 MB per step over xGMI (~0.4 ms) against a 28 ms step.
+Data-parallel ranks (an ``averager``) replay the step as a *chain of graphs with the collectives between them*, so
+that the RCCL all-reduces overlap the backward pass although no collective sits inside a captured graph:
+
+    segment 0 = forward + loss + backward down to the last gradient of bucket 0 + that bucket's gather
+    -> all-reduce of bucket 0 goes on RCCL's stream (it waits for segment 0 only)
+    segment 1 = backward down to the last gradient of bucket 1 + gather      (runs while bucket 0 is on the wire)
+    -> all-reduce of bucket 1 ...
+    last segment = the rest of backward (+ buckets no gradient reported to) -> the last, small bucket (parallel.py)
+    update graph = 1/world scale + AdamW + dropout-stream advance            (after the compute stream has waited for
+                                                                              the collectives)
+
+The cut points are found while capturing: the hook of a bucket's last gradient (`GradientAverager.on_bucket`, on
+autograd's device thread) ends the running capture and begins the next one on the same stream and memory pool -- which
+needs ``capture_error_mode="relaxed"`` (a stream capture may otherwise only be ended by the thread that began it).  A
+rank issues (number of buckets + 1) graph launches and as many collectives per step instead of ~480 kernel launches:
+the host stays off the critical path when eight ranks share one CPU.
 """
+import gc
 import os
 
 import torch
@@ -36,7 +47,8 @@ class TrainStep:
         # collectives stay outside captured graphs (see parallel.py): with an averager the step is two graphs
         self.use_graph = bool(use_graph)
         self.graph = None
-        self.graph_b = None          # data-parallel: scale + optimizer update (graph A = self.graph: forward + backward)
+        self.graph_b = None          # data-parallel: scale + optimizer update
+        self.segments = []           # data-parallel: [(graph, bucket indices to put on the wire after it)]; graph = segment 0
         self.shape = None            # shapes the graph was captured for
         self._eager_shape = None     # shapes of the last eager step (the capture follows an eager step of its shape)
         self._x = self._y = self._loss = None
@@ -106,28 +118,14 @@ class TrainStep:
                 with torch.cuda.graph(graph):
                     self._loss = self.eager(self._x, self._y)
             else:
-                av.deferred = True                    # hooks gather into the flat buffers, no collective while capturing
-                try:
-                    with torch.cuda.graph(graph):
-                        self._loss = self._fwd_bwd(self._x, self._y).detach()
-                        av.gather_remaining()
-                finally:
-                    av.deferred = False
-                # a capture records, it does not run: nothing has been computed yet.  The update graph is captured right
-                # away (its inputs -- the flat buffers the gradients are averaged in -- have fixed addresses), and the
-                # caller replays both with the collectives in between.
-                av.expose()
-                graph_b = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_b, pool=graph.pool()):
-                    av.scale_all()
-                    self._update()
-                self.graph_b = graph_b
+                graph = self._capture_segments(self._x, self._y)
         except Exception:
             # nothing of the failed capture ran on the device; restore the host-side bookkeeping it touched and let the
             # caller run this shape kernel by kernel from now on
             ops._Rng.local = rng_local
             self._x = self._y = self._loss = None
             self.graph = self.shape = self.graph_b = None
+            self.segments = []
             if av is not None:
                 for b in av.buckets:
                     b["pending"], b["gathered"], b["handle"] = len(b["params"]), False, None
@@ -137,8 +135,79 @@ class TrainStep:
         self.graph, self.shape = graph, (tuple(x.shape), tuple(y.shape))
         self._opt_epoch = getattr(self.opt, "table_epoch", None)
 
+    def _capture_segments(self, x, y):
+        """data-parallel capture: forward + backward as one graph per gradient bucket (module docstring), then the update
+        graph.  Returns segment 0."""
+        av = self.averager
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.empty_cache()                      # (what torch.cuda.graph() does on entry)
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        pool = torch.cuda.graph_pool_handle()
+        segments = []                                 # [graph, [bucket indices]]
+        waiting = {"n": len(av.buckets)}
+
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            g.capture_begin(pool=pool, capture_error_mode="relaxed")
+            segments.append([g, []])
+
+        def on_bucket(index):                         # autograd's device thread, inside loss.backward()
+            segments[-1][1].append(index)
+            waiting["n"] -= 1
+            if waiting["n"] > 0:                      # (the last bucket's segment also takes the rest of backward)
+                segments[-1][0].capture_end()
+                begin()
+
+        av.deferred, av.on_bucket = True, on_bucket
+        try:
+            with torch.cuda.stream(stream):
+                begin()
+                try:
+                    self._loss = self._fwd_bwd(x, y).detach()
+                    av.gather_remaining()             # buckets some parameter never reported to
+                    segments[-1][0].capture_end()
+                except BaseException:
+                    try:                              # never leave the stream capturing
+                        segments[-1][0].capture_end()
+                    except Exception:                 # noqa: BLE001
+                        pass
+                    raise
+                seen = {i for _, ids in segments for i in ids}
+                segments[-1][1] += [b["index"] for b in av.buckets if b["index"] not in seen]
+                # a capture records, it does not run: nothing has been computed yet.  The update graph is captured right
+                # away (its inputs -- the flat buffers the gradients are averaged in -- have fixed addresses).
+                av.expose()
+                graph_b = torch.cuda.CUDAGraph()
+                graph_b.capture_begin(pool=pool, capture_error_mode="relaxed")
+                try:
+                    av.scale_all()
+                    self._update()
+                finally:
+                    graph_b.capture_end()
+        finally:
+            av.deferred, av.on_bucket = False, None
+            torch.cuda.current_stream().wait_stream(stream)
+        self.segments = [(g, tuple(ids)) for g, ids in segments]
+        self.graph_b = graph_b
+        return segments[0][0]
+
+    def _agree(self, ok, device):
+        """data-parallel ranks replay graphs only if every rank captured: a rank that fell back to the kernel-by-kernel
+        loop on its own would still pair its collectives with the others' (same buckets, same order), but the decision
+        is made once, together"""
+        av = self.averager
+        if av is None or av.world <= 1:
+            return ok
+        import torch.distributed as dist
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=av.group)
+        return bool(flag.item())
+
     def _drop_graph(self):
         self.graph = self.shape = self.graph_b = None
+        self.segments = []
         self._x = self._y = self._loss = None
         self._eager_shape = None
         self._old_tables.clear()
@@ -163,7 +232,14 @@ class TrainStep:
                 return self.eager(x, y)
             try:
                 self._capture(x, y)
+                ok = True
             except RuntimeError:
+                ok = False
+            if not self._agree(ok, x.device):
+                if ok:
+                    self._drop_graph()
+                    self.opt.zero_grad(set_to_none=True)
+                    self.opt.invalidate_grad_table()
                 self._no_graph_shapes.add(shape)
                 return self.eager(x, y)
         if shape != self.shape:
@@ -173,10 +249,17 @@ class TrainStep:
         if y.data_ptr() != self._y.data_ptr():
             self._y.copy_(y)
         self.opt.sync_hyper()                        # ReduceLROnPlateau may have changed the learning rate
-        self.graph.replay()
-        if self.averager is not None:                # collectives between the two graphs of a data-parallel step
-            self.averager.launch_all()
-            self.averager.wait_all()
+        if self.averager is None:
+            self.graph.replay()
+        else:
+            # one graph per gradient bucket, each bucket on the wire as soon as its segment is enqueued: the collective
+            # waits (on RCCL's stream) for that segment only and runs under the following ones
+            av = self.averager
+            for g, bucket_ids in self.segments:
+                g.replay()
+                for i in bucket_ids:
+                    av.launch(i)
+            av.wait_all()                            # the compute stream waits; the host does not (RCCL)
             self.graph_b.replay()
         self.replays += 1
         self.opt.note_steps(1)                       # host mirrors of what the graph did on the device

@@ -62,8 +62,8 @@ torch.cuda.synchronize()
 with torch.cuda.stream(s):
     g = torch.cuda.CUDAGraph()
     state["stream"] = s
-    g.capture_begin(capture_error_mode="relaxed")
-    state["pool"] = g.pool()
+    state["pool"] = torch.cuda.graph_pool_handle()
+    g.capture_begin(pool=state["pool"], capture_error_mode="relaxed")
     state["cur"] = g
     graphs.append(g)
     loss = fwd(x)

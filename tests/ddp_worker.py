@@ -7,8 +7,9 @@ grads: tiny:CNN (no BatchNorm, no batch-axis attention; eval mode switches dropo
        of the two half batches must equal the gradients of the full batch computed by the same HIP model.
 step : two data-parallel train steps of tiny:SAUnet (BN statistics and attention stay rank-local); parameters must stay
        bit-identical across the ranks.
-graph: the same loop through step.TrainStep with an averager: forward + backward and the update replayed as two HIP graphs
-       with the bucketed all-reduces between them; 5 steps, against the kernel-by-kernel data-parallel loop.
+graph: the same loop through step.TrainStep with an averager: forward + backward replayed as one HIP graph per gradient
+       bucket with each bucket's all-reduce launched behind its segment (overlapping the following ones), then the update
+       graph; 5 steps, against the kernel-by-kernel data-parallel loop.
 """
 import json
 import os
@@ -113,6 +114,7 @@ def main():
             avg.remove()
             return dict(losses=losses, flat=flat, identical=all(bool(torch.equal(both[0], b)) for b in both[1:]),
                         replays=ts.replays, graphs=(ts.graph is not None, ts.graph_b is not None),
+                        segments=[list(ids) for _, ids in ts.segments], buckets=len(avg.buckets),
                         opt_steps=int(next(iter(opt.state.values()))["step"]))
         runs = {g: run("tiny:SAUnet", g) for g in (False, True)}
         cnn = {g: run("tiny:CNN", g) for g in (False, True)}
@@ -121,6 +123,7 @@ def main():
         out.update(losses=runs[True]["losses"], losses_eager=runs[False]["losses"],
                    params_identical=runs[True]["identical"] and runs[False]["identical"] and cnn[True]["identical"],
                    finite=bool(torch.isfinite(b).all()), replays=runs[True]["replays"], graphs=runs[True]["graphs"],
+                   segments=runs[True]["segments"], buckets=runs[True]["buckets"],
                    graph_vs_eager=float((a - b).abs().max() / a.abs().max()), opt_steps=runs[True]["opt_steps"],
                    cnn_graph_vs_eager=float((ca - cb).abs().max() / ca.abs().max()),
                    cnn_loss_dev=max(abs(u - v) for u, v in zip(cnn[True]["losses"], cnn[False]["losses"])))

@@ -24,10 +24,10 @@ def dev():
 
 
 @pytest.fixture(autouse=True)
-def _head_forward_at_any_batch(monkeypatch):
+def _head_forward_at_any_batch(setenv_diag):
     """the planner hands small launches of the forward pass to the generic kernel (conv_plan.h: plan_head); the cases here are
     small, so switch that off -- what is under test is the kernel"""
-    monkeypatch.setenv("MPA_HEAD_FWD_MIN_WGS", "0")
+    setenv_diag("MPA_HEAD_FWD_MIN_WGS", "0")
 
 
 def _rand(shape, seed, scale=1.0):
@@ -103,14 +103,14 @@ def test_head_conv_is_bit_reproducible_and_has_no_atomics(dev):
         assert torch.equal(a, b)
 
 
-def test_head_conv_switch_off_gives_the_generic_kernels(dev, monkeypatch):
-    monkeypatch.setenv("MPA_HEAD_OFF", "1")
+def test_head_conv_switch_off_gives_the_generic_kernels(dev, setenv_diag):
+    setenv_diag("MPA_HEAD_OFF", "1")
     assert _plan((2, 128, 75, 216, 80), 0).startswith("fwd<")
     assert _plan((2, 128, 75, 216, 80), 2).startswith("wgrad")
 
 
-def test_head_forward_goes_to_the_generic_kernel_for_small_launches(dev, monkeypatch):
-    monkeypatch.delenv("MPA_HEAD_FWD_MIN_WGS")
+def test_head_forward_goes_to_the_generic_kernel_for_small_launches(dev, setenv_diag):
+    setenv_diag("MPA_HEAD_FWD_MIN_WGS", None)
     assert _plan((16, 128, 75, 216, 80), 0).startswith("fwd<")             # 272 workgroups: the generic kernel fills the chip better
     assert _plan((32, 128, 75, 216, 80), 0).startswith("head_gemm<5,1,4>")
     assert _plan((32, 128, 75, 216, 80), 1).startswith("head_gemm<6,4,2>")  # backward passes: at every batch

@@ -592,7 +592,7 @@ def test_conv_backward_weight_global_dy_variants(dev, case):
 @pytest.mark.parametrize("geom", [(20, 1), (32, 1), (24, 1), (48, 3), (17, 1), (27, 1), (30, 1), (45, 1), (54, 1)],
                          ids=["w20-tail1", "w32-notail", "w24-tail2", "w48-stride3", "w17-edge", "w27-edge", "w30-edge4",
                               "w45-edge4", "w54-edge"])
-def test_conv_backward_weight_every_global_dy_kernel(dev, variant, geom, monkeypatch):
+def test_conv_backward_weight_every_global_dy_kernel(dev, variant, geom, setenv_diag):
     """the planner normally picks one wave-tile variant per problem by cost; pin each of the five (x tail / no tail, and
     the stride-3 build of the 80-cout variant) with the planner's test switches so that every instantiation is checked"""
     import ctypes
@@ -602,9 +602,9 @@ def test_conv_backward_weight_every_global_dy_kernel(dev, variant, geom, monkeyp
         pytest.skip("stride 3 exists for the 80-cout variant only")
     if W % 4 and variant != 1:
         pytest.skip("unaligned rows exist for the <2,8> variant only")
-    monkeypatch.setenv("MPA_WG_GA", "force")
-    monkeypatch.setenv("MPA_WG_VARIANT", str(variant))
-    monkeypatch.setenv("MPA_HEAD_OFF", "1")            # stride 3: the generic kernel under test, not conv_head.hip
+    setenv_diag("MPA_WG_GA", "force")
+    setenv_diag("MPA_WG_VARIANT", str(variant))
+    setenv_diag("MPA_HEAD_OFF", "1")            # stride 3: the generic kernel under test, not conv_head.hip
     B, Cin, H, Cout, k = 2, 21, 7, 37, 3
     pad = (1, 1) if sw == 1 else (1, 0)
     d = L.ConvDesc(B, Cin, H, W, Cout, k, k, 1, sw, pad[0], pad[1])
@@ -786,12 +786,12 @@ def test_conv15_cout_remainder_fold(dev, case):
     _close(bg.grad, br.grad, 5e-5, "db")
 
 
-def test_conv15_fold_switch(dev, monkeypatch):
+def test_conv15_fold_switch(dev, setenv_diag):
     import ctypes
     from multipitch_architectures_amd import _lib as L
     d = L.ConvDesc(2, 70, 20, 40, 70, 15, 15, 1, 1, 7, 7)
     assert L.load().mpa_conv2d_fold_supported(ctypes.byref(d)) == 1
-    monkeypatch.setenv("MPA_FOLD_OFF", "1")
+    setenv_diag("MPA_FOLD_OFF", "1")
     assert L.load().mpa_conv2d_fold_supported(ctypes.byref(d)) == 0
 
 

@@ -84,12 +84,17 @@ def test_exactness_modes_reproduce_the_full_batch_run(backend):
 
 
 @pytest.mark.parametrize("backend", _backends())
-def test_data_parallel_step_as_two_graphs_matches_the_kernel_by_kernel_loop(backend):
-    """step.TrainStep with an averager: graph A (forward + backward + bucket gathers), the all-reduces from the host, graph B
-    (scale + AdamW + dropout-stream advance) -- same losses and parameters as the kernel-by-kernel data-parallel loop"""
+def test_data_parallel_step_as_graph_segments_matches_the_kernel_by_kernel_loop(backend):
+    """step.TrainStep with an averager: forward + backward captured as one graph per gradient bucket (cut from the bucket's
+    last gradient hook), each bucket's all-reduce launched from the host behind its segment, then the update graph (scale +
+    AdamW + dropout-stream advance) -- same losses and parameters as the kernel-by-kernel data-parallel loop, parameters
+    bit-identical across the ranks"""
     res = _run(backend, "graph")
     for r in res:
         assert r["graphs"] == [True, True] and r["replays"] == 4, r       # step 1 kernel by kernel, steps 2..5 replayed
+        # one segment per bucket, every bucket launched exactly once, in the order the gradients complete
+        assert len(r["segments"]) == r["buckets"] > 2, r
+        assert sorted(i for ids in r["segments"] for i in ids) == list(range(r["buckets"])), r
         assert r["params_identical"] and r["finite"] and r["opt_steps"] == 5, r
         # tiny:SAUnet at 4 patches per rank is chaotic under train-mode BatchNorm (backward-data adds channel slices
         # atomically, so even two kernel-by-kernel runs differ in the last bits): the first steps agree tightly, the
@@ -111,5 +116,6 @@ def test_single_rank_rccl_communicator_runs_the_same_path(case):
         assert r["buckets"] > 1 and r["rel_err"] < 2e-5, r
     elif case == "graph":
         assert r["graphs"] == [True, True] and r["replays"] == 4 and r["cnn_graph_vs_eager"] < 3e-4 and r["finite"], r
+        assert len(r["segments"]) == r["buckets"] > 2, r
     else:
         assert r["params_identical"] and r["finite"] and all(0 < v < 10 for v in r["losses"]), r
