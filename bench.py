@@ -312,6 +312,34 @@ def bf16x3_probe(model, criterion, opt, x, y, args, probe, kflops, gflop_table):
     return res
 
 
+def t174_probe(model, criterion, opt, args, batch=64, frames=174):
+    """SURVEY 8(d)'s secondary shape -- patches of 174 frames (100 output frames each; the shape of the north_star and of the
+    reference's torchinfo summaries) -- as a labelled second measurement of the same model and step, timed after the
+    headline region; never the line's `value`."""
+    from multipitch_architectures_amd.configs import TRAIN_GFLOP_PER_PATCH_T174
+    from multipitch_architectures_amd.step import TrainStep
+    from multipitch_architectures_amd.synth import synth_batch
+    dev = next(model.parameters()).device
+    x, y = synth_batch(batch, frames, seed=1234)
+    x, y = x.to(dev), y.to(dev)
+    ts = TrainStep(model, criterion, opt, use_graph=not args.no_graph)
+    for _ in range(3):
+        ts(x, y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ts(x, y)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    res = {"workload": f"{args.config} train step, batch {batch}, patches (6,{frames},216) -> ({frames - 74},72)",
+           "global_batch": batch, "frames": frames, "ms_per_step": dt * 1e3, "patches_per_s": batch / dt,
+           "value": batch * (frames - 74) / dt, "unit": "frames/s", "dtype": "f32", "hip_graph": ts.graph is not None}
+    if args.config in TRAIN_GFLOP_PER_PATCH_T174 and frames == 174:
+        res["step_tflops"] = TRAIN_GFLOP_PER_PATCH_T174[args.config] * batch / dt / 1e3
+        res["step_mfma_frac"] = res["step_tflops"] / PEAK_FP32_MFMA_TFLOPS
+    return res
+
+
 def main():
     args = parse_args()
     # stdout carries exactly ONE line, the JSON: libraries that print banners to file descriptor 1 (RCCL's version block
@@ -511,6 +539,9 @@ def main():
             "hip_graph": graphed,
             "host_enqueue_ms_per_step": host_ms,      # per rank: host time to enqueue one step (graph replays + collectives)
             "dp_graphs": bool(dp and graphed and train_step.graph_b is not None),
+            # data-parallel replay: one graph per gradient bucket, bucket k's all-reduce launched behind segment k
+            "dp_segments": [list(ids) for _, ids in train_step.segments] if dp and graphed else None,
+            "dp_bucket_mb": [round(b["flat"].numel() * 4 / 2 ** 20, 2) for b in averager.buckets] if averager else None,
             "dp_exactness": {"sync_bn": bool(args.sync_bn), "gather_attention": bool(args.gather_attention)},
         }
         if args.config in TRAIN_GFLOP_PER_PATCH and args.frames == 75:     # the FLOP table is for T = 75 patches
@@ -522,6 +553,9 @@ def main():
                                               "bf16 MFMA, so values above 1 are expected")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, args.frames)
+        if world == 1 and not args.no_extras and not bfx and not args.dp_rehearsal and args.config == "SAUnet:L" \
+                and args.frames == 75:
+            out["t174"] = t174_probe(model, criterion, opt, args)
         if world == 1 and not args.no_extras and not bfx and not args.dp_rehearsal:
             out["bf16x3"] = bf16x3_probe(model, criterion, opt, x, y, args, probe, kflops, TRAIN_GFLOP_PER_PATCH)
         if world == 1 and not args.no_extras:

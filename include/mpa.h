@@ -150,6 +150,8 @@ int mpa_bn_relu_eval_fwd(const float* x, const float* gamma, const float* beta, 
                          const float* running_var, float* y, float* save_mean /*nullable*/, float* save_invstd /*nullable*/,
                          int B, int C, int HW, float eps, int relu, void* stream);
 /* dx, dgamma, dbeta from dy (grad w.r.t. the post-ReLU output y). train!=0: batch-stat backward.
+ * stats_ws: 128 * C doubles of scratch (up to 64 partial pairs of sums per channel, added in a fixed order: no zero-fill,
+ * no atomics -- run-to-run reproducible).
  * ReLU mask: with beta != NULL it is recomputed from x with the forward's own arithmetic and y is never read
  * (y may then be NULL); with beta == NULL it is y > 0.                                                          */
 int mpa_bn_relu_bwd(const float* dy, const float* x, const float* y /*nullable*/, const float* gamma,
@@ -181,10 +183,17 @@ int mpa_maxpool2d_fwd(const float* x, float* y, int32_t* idx, int B, int C, int 
                       int sh, int sw, int ph, int pw, void* stream);
 int mpa_maxpool2d_bwd(const float* dy, const int32_t* idx, float* dx, int B, int C, int H, int W, int kh, int kw,
                       int sh, int sw, int ph, int pw, void* stream);
+/* dx = maxpool backward of dy + add: the tensor that was pooled also fed a second consumer (the U-Net's skip connection,
+ * unet_cnns.py:562-571: x1..x4 go into the next level's MaxPool2d and into unet_up_concat_padding) and `add` is that
+ * consumer's gradient -- C planes of H*W floats per sample, samples add_batch_stride floats apart (the first Cs channels of
+ * the concatenated gradient, read in place).  One pass instead of the pool backward, a slice copy and an add.            */
+int mpa_maxpool2d_bwd_add(const float* dy, const int32_t* idx, const float* add /*nullable*/, int64_t add_batch_stride,
+                          float* dx, int B, int C, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, void* stream);
 /* unet_up_concat_padding (unet_cnns.py:93-104): out = cat([skip, pad(bilinear_x2_align_corners(x1))], dim=1) */
 int mpa_upcat_fwd(const float* x1, const float* skip, float* out, int B, int C1, int H1, int W1, int Cs, int Hs,
                   int Ws, void* stream);
-int mpa_upcat_bwd(const float* dout, float* dx1, float* dskip, int B, int C1, int H1, int W1, int Cs, int Hs,
+/* dskip == NULL: only dx1 is formed (the caller reads the skip half dout[:, :Cs] in place, mpa_maxpool2d_bwd_add) */
+int mpa_upcat_bwd(const float* dout, float* dx1, float* dskip /*nullable*/, int B, int C1, int H1, int W1, int Cs, int Hs,
                   int Ws, void* stream);
 
 /* ------------------------------------------------------------------ pointwise

@@ -83,6 +83,9 @@ BASELINE_CONFIGS = [("CNN:XS", 8), ("DRCNN:L", 64), ("Unet:L", 128), ("SAUnet:L"
 # algorithmic train-step GFLOP per patch at T=75 (fwd+dgrad+wgrad)
 TRAIN_GFLOP_PER_PATCH = {"DRCNN:L": 436.32, "Unet:L": 88.25, "SAUnet:L": 86.67, "BLUnet:XXL": 91.01,
                          "PUnet:XL": 243.93}
+# the same at T=174 (100 output frames per patch, SURVEY 8(d)'s secondary shape): 6 x forward GMAC (SURVEY's table) minus
+# 2 x the first convolution's (no input gradient): SAUnet:L 6 x 36.071 - 2 x 0.8118
+TRAIN_GFLOP_PER_PATCH_T174 = {"SAUnet:L": 214.80}
 FWD_GMAC_PER_PATCH = {"CNN:XS": 0.458, "DRCNN:L": 73.230, "Unet:L": 14.825, "SAUnet:L": 14.562,
                       "BLUnet:XXL": 15.285, "PUnet:XL": 40.888}
 

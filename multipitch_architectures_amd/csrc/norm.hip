@@ -413,9 +413,12 @@ __global__ void bn_eval_save_kernel(const float* rmean, const float* rvar, float
 }
 
 // backward sums: S1 = sum g, S2 = sum g*xhat, g = dy * (y>0)
-template <int V>
 // ReLU mask: with `beta` given it is recomputed from x exactly as bn_apply_kernel formed y (x*sc + sf > 0, same float
 // operations), so y is never read; without beta it is y > 0.
+// PART: the block leaves its pair of sums in stats[(c * gridDim.x + blockIdx.x) * 2 ..] (bn_bwd_apply_kernel adds the
+// gridDim.x <= 64 pairs of its channel in a fixed order: no zero-fill launch, no atomics, run-to-run reproducible);
+// otherwise the blocks add into the zeroed stats[2 c ..] atomically (the SyncBN halves, which hand 2 C sums to the caller).
+template <int V, bool PART>
 __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ y, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ save_mean,
@@ -468,11 +471,19 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
   if (lane == 0) { sh[wave * 2] = ds; sh[wave * 2 + 1] = dq; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(&stats[2 * c], sh[0] + sh[2] + sh[4] + sh[6]);
-    atomicAdd(&stats[2 * c + 1], sh[1] + sh[3] + sh[5] + sh[7]);
+    if (PART) {
+      double* o = stats + ((long)c * gridDim.x + blockIdx.x) * 2;
+      o[0] = sh[0] + sh[2] + sh[4] + sh[6];
+      o[1] = sh[1] + sh[3] + sh[5] + sh[7];
+    } else {
+      atomicAdd(&stats[2 * c], sh[0] + sh[2] + sh[4] + sh[6]);
+      atomicAdd(&stats[2 * c + 1], sh[1] + sh[3] + sh[5] + sh[7]);
+    }
   }
 }
 
+// nsplit > 0: stats holds nsplit <= 64 partial pairs per channel (bn_bwd_stats_kernel<V, true>); every wave adds its
+// channel's pairs itself (one pair per lane, butterfly sum: the same value in every wave of every block)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ y, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta,
@@ -480,20 +491,30 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ save_invstd,
                                                            const double* __restrict__ stats, float* __restrict__ dx, int C,
                                                            int HW, double count, int relu, int train,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int nsplit) {
   const int plane = blockIdx.x, c = plane % C;
+  double s1, s2;
+  if (nsplit > 0) {
+    const int lane = threadIdx.x & 63;
+    const double* pp = stats + ((long)c * nsplit + (lane < nsplit ? lane : 0)) * 2;
+    s1 = mpa_wave_sum_d(lane < nsplit ? pp[0] : 0.0);
+    s2 = mpa_wave_sum_d(lane < nsplit ? pp[1] : 0.0);
+  } else {
+    s1 = stats[2 * c];
+    s2 = stats[2 * c + 1];
+  }
   // the parameter gradients are the two sums themselves: written here by the first image's blocks instead of by an 18th-of-a-
   // step launch of their own (dgamma != nullptr)
   if (dgamma != nullptr && plane < C && blockIdx.y == 0 && threadIdx.x == 0) {
-    dbeta[c] = (float)stats[2 * c];
-    dgamma[c] = (float)stats[2 * c + 1];
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
   }
   const float mu = save_mean[c], is = save_invstd[c];
   const float k = gamma[c] * is;
   const bool from_x = beta != nullptr;              // ReLU mask recomputed from x (see bn_bwd_stats_kernel)
   const float sf = from_x ? beta[c] - mu * k : 0.f;
-  const float m1 = train ? (float)(stats[2 * c] / count) : 0.f;
-  const float m2 = train ? (float)(stats[2 * c + 1] / count) : 0.f;
+  const float m1 = train ? (float)(s1 / count) : 0.f;
+  const float m2 = train ? (float)(s2 / count) : 0.f;
   const long base = (long)plane * HW;
   if ((HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx) |
                          reinterpret_cast<uintptr_t>(y)) & 15) == 0) {
@@ -538,6 +559,7 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ stats, float* 
   dgamma[c] = (float)stats[2 * c + 1];
 }
 
+#define MPA_BN_BWD_SPLITS 64      // partial pairs per channel bn_bwd_apply_kernel sums (one per lane)
 inline int stat_splits(int B, int C, int HW) {
   long per = (long)B * HW;
   long want = std::max<long>(1, (256L * 16) / C);
@@ -673,18 +695,18 @@ int mpa_bn_relu_bwd(const float* dy, const float* x, const float* y, const float
     return MPA_ERR_ARG;
   if (!y) y = x;      // never dereferenced when beta is given; keeps the alignment test below meaningful
   hipStream_t s = (hipStream_t)stream;
-  if (mpa_zero_async(stats_ws, sizeof(double) * 2 * C, s) != MPA_OK) return MPA_ERR_LAUNCH;
   if ((long)B * HW > 0x7fffffffL) return MPA_ERR_ARG;
-  const int splits = stat_splits(B, C, HW);
+  // two launches, no zero-fill: at most MPA_BN_BWD_SPLITS partial pairs per channel, summed by the apply kernel's waves
+  const int splits = std::min(stat_splits(B, C, HW), MPA_BN_BWD_SPLITS);
   const bool vec = HW % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) |
                                     reinterpret_cast<uintptr_t>(y)) & 15) == 0;
-  if (vec) MPA_LAUNCH(bn_bwd_stats_kernel<4>, dim3(splits, C), dim3(256), 0, s, dy, x, y, gamma, beta, save_mean,
+  if (vec) MPA_LAUNCH((bn_bwd_stats_kernel<4, true>), dim3(splits, C), dim3(256), 0, s, dy, x, y, gamma, beta, save_mean,
                       save_invstd, stats_ws, B, C, HW, relu);
-  else MPA_LAUNCH(bn_bwd_stats_kernel<1>, dim3(splits, C), dim3(256), 0, s, dy, x, y, gamma, beta, save_mean, save_invstd,
+  else MPA_LAUNCH((bn_bwd_stats_kernel<1, true>), dim3(splits, C), dim3(256), 0, s, dy, x, y, gamma, beta, save_mean, save_invstd,
                   stats_ws, B, C, HW, relu);
   const int chunks = (int)std::max<long>(1, std::min<long>(mpa_cdiv(HW, 1024), 64));
   MPA_LAUNCH(bn_bwd_apply_kernel, dim3(B * C, chunks), dim3(256), 0, s, dy, x, y, gamma, beta, save_mean, save_invstd,
-                     (const double*)stats_ws, dx, C, HW, (double)B * HW, relu, train, dgamma, dbeta);
+                     (const double*)stats_ws, dx, C, HW, (double)B * HW, relu, train, dgamma, dbeta, splits);
   return mpa_launch_status();
 }
 
@@ -725,9 +747,9 @@ int mpa_bn_relu_bwd_sums(const float* dy, const float* x, const float* gamma, co
   if (mpa_zero_async(stats, sizeof(double) * 2 * C, s) != MPA_OK) return MPA_ERR_LAUNCH;
   const int splits = stat_splits(B, C, HW);
   const bool vec = HW % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
-  if (vec) MPA_LAUNCH(bn_bwd_stats_kernel<4>, dim3(splits, C), dim3(256), 0, s, dy, x, x, gamma, beta, save_mean, save_invstd,
+  if (vec) MPA_LAUNCH((bn_bwd_stats_kernel<4, false>), dim3(splits, C), dim3(256), 0, s, dy, x, x, gamma, beta, save_mean, save_invstd,
                       stats, B, C, HW, relu);
-  else MPA_LAUNCH(bn_bwd_stats_kernel<1>, dim3(splits, C), dim3(256), 0, s, dy, x, x, gamma, beta, save_mean, save_invstd, stats,
+  else MPA_LAUNCH((bn_bwd_stats_kernel<1, false>), dim3(splits, C), dim3(256), 0, s, dy, x, x, gamma, beta, save_mean, save_invstd, stats,
                   B, C, HW, relu);
   // this rank's parameter gradients come from its own sums (the gradient averager sums them over the ranks)
   MPA_LAUNCH(bn_bwd_finalize_kernel, dim3((unsigned)mpa_cdiv(C, 64)), dim3(64), 0, s, (const double*)stats, dgamma, dbeta, C);
@@ -741,7 +763,7 @@ int mpa_bn_relu_bwd_apply(const float* dy, const float* x, const float* gamma, c
   hipStream_t s = (hipStream_t)stream;
   const int chunks = (int)std::max<long>(1, std::min<long>(mpa_cdiv(HW, 1024), 64));
   MPA_LAUNCH(bn_bwd_apply_kernel, dim3(B * C, chunks), dim3(256), 0, s, dy, x, x, gamma, beta, save_mean, save_invstd, stats,
-             dx, C, HW, count, relu, 1, (float*)nullptr, (float*)nullptr);
+             dx, C, HW, count, relu, 1, (float*)nullptr, (float*)nullptr, 0);
   return mpa_launch_status();
 }
 

@@ -37,13 +37,17 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
 
 // gather form: every input element sums dy of the windows whose recorded argmax it is (deterministic, no atomics);
 // one wave per input row (plane, iy)
+// add (nullable): a second gradient of the pooled tensor, summed into dx on the way out -- planes of H*W floats, C planes per
+// sample, samples add_bs floats apart (the skip half of a concatenated gradient, PoolSkipFn in ops.py)
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ idx,
                                                           float* __restrict__ dx, long rows, int H, int W, int OH,
-                                                          int OW, int kh, int kw, int sh, int sw, int ph, int pw) {
+                                                          int OW, int kh, int kw, int sh, int sw, int ph, int pw,
+                                                          const float* __restrict__ add, int C, long add_bs) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
     const long pl = r / H;
     const int iy = (int)(r - pl * H);
+    const float* arow = add ? add + (pl / C) * add_bs + (pl % C) * (long)H * W + (long)iy * W : nullptr;
     // windows oy with oy*sh - ph <= iy <= oy*sh - ph + kh - 1
     int oy_lo = (iy + ph - kh + 1 + sh - 1);
     oy_lo = oy_lo <= 0 ? 0 : oy_lo / sh;
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
           const long o = ob + (long)oy * OW + ox;
           if (idx[o] == me) s += dy[o];
         }
-      dx[r * W + ix] = s;
+      dx[r * W + ix] = arow ? s + arow[ix] : s;
     }
   }
 }
@@ -208,11 +212,22 @@ __global__ __launch_bounds__(256) void maxpool_col_bwd_kernel(const float* __res
 // with an LDS float atomic, then the plane is written out with contiguous stores -- one LDS operation per *window*
 // instead of kh*kw argmax tests per input element (13 for the head's 13x1 stride-1 pool).  Where several overlapping
 // windows share an argmax the order of the fp32 adds is not fixed.
+// add / C / add_bs as in maxpool_bwd_kernel: the LDS plane starts from the second gradient instead of from zeros
 __global__ __launch_bounds__(256) void maxpool_bwd_plane_kernel(const float* __restrict__ dy, const int32_t* __restrict__ idx,
-                                                                float* __restrict__ dx, int n_in, int n_out) {
+                                                                float* __restrict__ dx, int n_in, int n_out,
+                                                                const float* __restrict__ add, int C, long add_bs) {
   extern __shared__ float plane[];
   const long pl = blockIdx.x;
-  for (int i = threadIdx.x; i < n_in; i += 256) plane[i] = 0.f;
+  if (add) {
+    const float* ap = add + (pl / C) * add_bs + (pl % C) * (long)n_in;
+    if ((n_in & 3) == 0 && ((reinterpret_cast<uintptr_t>(ap)) & 15) == 0) {
+      for (int i = threadIdx.x * 4; i < n_in; i += 1024) *reinterpret_cast<float4*>(plane + i) = *reinterpret_cast<const float4*>(ap + i);
+    } else {
+      for (int i = threadIdx.x; i < n_in; i += 256) plane[i] = ap[i];
+    }
+  } else {
+    for (int i = threadIdx.x; i < n_in; i += 256) plane[i] = 0.f;
+  }
   __syncthreads();
   const float* g = dy + pl * n_out;
   const int32_t* am = idx + pl * n_out;
@@ -629,10 +644,15 @@ int mpa_maxpool2d_fwd(const float* x, float* y, int32_t* idx, int B, int C, int 
 
 int mpa_maxpool2d_bwd(const float* dy, const int32_t* idx, float* dx, int B, int C, int H, int W, int kh, int kw, int sh,
                       int sw, int ph, int pw, void* stream) {
-  if (!dy || !idx || !dx) return MPA_ERR_ARG;
+  return mpa_maxpool2d_bwd_add(dy, idx, nullptr, 0, dx, B, C, H, W, kh, kw, sh, sw, ph, pw, stream);
+}
+
+int mpa_maxpool2d_bwd_add(const float* dy, const int32_t* idx, const float* add, int64_t add_batch_stride, float* dx, int B, int C,
+                          int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, void* stream) {
+  if (!dy || !idx || !dx || (add && add_batch_stride < (int64_t)C * H * W)) return MPA_ERR_ARG;
   const int OH = (H + 2 * ph - kh) / sh + 1, OW = (W + 2 * pw - kw) / sw + 1;
   const long planes = (long)B * C;
-  if (kh == 13 && kw == 1 && sh == 1 && sw == 1 && pw == 0 && ph >= 0 && ph < 13) {
+  if (!add && kh == 13 && kw == 1 && sh == 1 && sw == 1 && pw == 0 && ph >= 0 && ph < 13) {
     const long items = planes * mpa_cdiv(H, 8) * W;
     MPA_LAUNCH((maxpool_col_bwd_kernel<13, 8>), dim3((unsigned)std::min<long>(mpa_cdiv(items, 256), 1 << 20)), dim3(256), 0,
                (hipStream_t)stream, dy, idx, dx, planes, H, W, OH, ph);
@@ -640,11 +660,11 @@ int mpa_maxpool2d_bwd(const float* dy, const int32_t* idx, float* dx, int B, int
   }
   if ((size_t)H * W * 4 <= PLANE_LDS_BYTES && planes <= 0x7fffffffL) {
     MPA_LAUNCH(maxpool_bwd_plane_kernel, dim3((unsigned)planes), dim3(256), (size_t)H * W * 4, (hipStream_t)stream, dy,
-               idx, dx, H * W, OH * OW);
+               idx, dx, H * W, OH * OW, add, C, (long)add_batch_stride);
     return mpa_launch_status();
   }
   MPA_LAUNCH(maxpool_bwd_kernel, dim3(row_blocks(planes * H)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx,
-                     planes * H, H, W, OH, OW, kh, kw, sh, sw, ph, pw);
+                     planes * H, H, W, OH, OW, kh, kw, sh, sw, ph, pw, add, C, (long)add_batch_stride);
   return mpa_launch_status();
 }
 
@@ -671,7 +691,22 @@ int mpa_upcat_fwd(const float* x1, const float* skip, float* out, int B, int C1,
 
 int mpa_upcat_bwd(const float* dout, float* dx1, float* dskip, int B, int C1, int H1, int W1, int Cs, int Hs, int Ws,
                   void* stream) {
-  if (!dout || !dx1 || !dskip) return MPA_ERR_ARG;
+  if (!dout || !dx1) return MPA_ERR_ARG;
+  if (!dskip) {
+    // the caller consumes the skip half in place (dout[:, :Cs], PoolSkipFn in ops.py): only dx1 is formed
+    const long rskip0 = (long)B * Cs * Hs, rx10 = (long)B * C1 * H1;
+    const bool al = ((long)Cs * Hs * Ws) % 4 == 0 && ((long)(Cs + C1) * Hs * Ws) % 4 == 0;
+    if (al && W1 < 32)
+      MPA_LAUNCH(upcat_bwd_flat_kernel, dim3(blocks_for(rx10 * W1)), dim3(256), 0, (hipStream_t)stream, dout, dx1, B, C1, H1, W1,
+                 Cs, Hs, Ws);
+    else if (al && W1 <= 128 && Ws <= 256)
+      MPA_LAUNCH(upcat_bwd_sep_kernel, dim3(row_blocks(rx10)), dim3(256), 0, (hipStream_t)stream, dout, dx1, B, C1, H1, W1, Cs,
+                 Hs, Ws);
+    else
+      MPA_LAUNCH(upcat_bwd_kernel, dim3(row_blocks(rx10)), dim3(256), 0, (hipStream_t)stream, dout, dx1, dskip, B, C1, H1, W1,
+                 Cs, Hs, Ws, rskip0);
+    return mpa_launch_status();
+  }
   if (((long)Cs * Hs * Ws) % 4 == 0 && ((long)(Cs + C1) * Hs * Ws) % 4 == 0) {
     // the skip half is a contiguous slab per sample: 16-byte copy; the gather kernel then only walks the dx1 rows
     // (an LDS-atomic scatter form was tried for dx1 and is 2x slower: neighbouring upsampled pixels share their source

@@ -69,8 +69,9 @@ def train(model, criterion, train_files, val_files, lr=1e-3, max_epochs=100, bat
     """train_files / val_files: lists of (inputs (6,T,216), targets (T,n_out)[, stride]) tuples.  Returns the per-epoch history.
     ``variant`` picks the experiment family's stride and per-epoch batch cap (``VARIANTS``); ``stride`` /
     ``max_batches`` override it.  ``use_graph``: the loop body (forward, loss, backward, AdamW) is captured once as a HIP
-    graph and replayed for every full-size batch (``step.TrainStep``); the last, smaller batch of an epoch and
-    data-parallel runs (``averager``) launch kernel by kernel."""
+    graph and replayed for every full-size batch (``step.TrainStep``); the last, smaller batch of an epoch launches kernel
+    by kernel.  Data-parallel runs (``averager``) replay one graph per gradient bucket with the bucket's all-reduce launched
+    behind it, overlapping the rest of backward (step.py)."""
     var = VARIANTS[variant]
     stride = var["stride"] if stride is None else stride
     max_batches = var["max_batches"] if max_batches is None else max_batches

@@ -84,7 +84,8 @@ class deep_cnn_segm_sigmoid(nn.Module):
                 if prefilt_layer._forward_hooks or prefilt_layer._forward_pre_hooks:
                     x = ops.add(prefilt_layer(x), x)             # a hooked stage returns x_new, as the reference's does
                 else:
-                    x = prefilt_layer.forward(x, residual=x)     # x_new + x: the add is part of the stage's last kernel
+                    xa, xb = ops.fanout(x)       # two consumers: their gradients are added by an in-tree kernel
+                    x = prefilt_layer.forward(xa, residual=xb)   # x_new + x: the add is part of the stage's last kernel
             else:
                 x = prefilt_layer(x)
         conv2_lrelu = self.conv2(x)

@@ -78,13 +78,12 @@ class double_conv(nn.Module):
             self.resize = Conv2d(in_channels, out_channels, kernel_size=(1, 1), padding=(0, 0))
 
     def forward(self, x):
-        x_conv = self.double_conv(x)
         if self.residual:
-            x_resized = self.resize(x)
-            x_out = ops.add(x_resized, x_conv)
-        else:
-            x_out = x_conv
-        return x_out
+            x, x_res = ops.fanout(x)                 # two consumers: their gradients are added by an in-tree kernel
+            x_conv = self.double_conv(x)
+            x_resized = self.resize(x_res)
+            return ops.add(x_resized, x_conv)
+        return self.double_conv(x)
 
 
 class unet_up_concat_padding(nn.Module):
@@ -159,12 +158,15 @@ class transformer_enc_layer(nn.Module):
             t = self.dropout_pe(ops.transpose_last2(xf, self._pe_on(x.device)))
         else:
             t = ops.transpose_last2(xf)                          # (B,S,E)
+        # t and x1_norm each feed a projection and a residual branch: explicit fan-outs, so that their two gradients are
+        # added by an in-tree kernel (ops.fanout) instead of by autograd's accumulation
+        t, t_res = ops.fanout(t)
         q, k, v = ops.qkv_linear(t, self.q_linear.weight, self.k_linear.weight, self.v_linear.weight)
         x1 = self.attn(q, k, v)[0]
         x1_proj = self.o_linear(x1)
-        x1_norm = self.layernorm1(t, self.dropout1(x1_proj))
+        x1_norm, x1_res = ops.fanout(self.layernorm1(t_res, self.dropout1(x1_proj)))
         x2 = self.mlp[2](self.mlp[0](x1_norm, ops.ACT_RELU))
-        x2_norm = self.layernorm2(x1_norm, self.dropout2(x2))
+        x2_norm = self.layernorm2(x1_res, self.dropout2(x2))
         return ops.transpose_last2(x2_norm).reshape(B, E, H, W)
 
 
@@ -222,13 +224,28 @@ class _UNetTrunk(nn.Module):
         self.upconv4 = double_conv(in_channels=128 // sc, out_channels=n_ch[0], mid_channels=128 // (sc * 2), **kp(ks[0]), **kw)
         self.conv2, self.conv3, self.conv4 = _head(n_ch[0], n_ch, n_bins_in, n_bins_out, a_lrelu, p_dropout)
 
+    @staticmethod
+    def _down(stage, x):
+        """stage(x) for stage = Sequential(MaxPool2d, double_conv), and x as the decoder will consume it.  When gradients
+        flow, the pooling and the hand-over to the skip connection are one autograd node (ops.pool_skip): the backward
+        pass then adds the two gradients of x inside the pool's backward kernel instead of in an accumulation kernel of
+        autograd.  Hooked modules go through nn.Module.__call__ as in the reference's nn.Sequential."""
+        pool = stage[0]
+        plain = not (torch.is_grad_enabled() and x.requires_grad and len(stage) == 2 and type(pool) is MaxPool2d)
+        for m in (stage, pool):
+            plain = plain or bool(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks)
+        if plain:
+            return stage(x), x
+        y, skip = ops.pool_skip(x, pool.kernel_size, pool.stride, pool.padding)
+        return stage[1](y), skip
+
     def _encode(self, x):
         x_norm = self.layernorm.forward_cf(x)
         x1 = self.inc(x_norm)
-        x2 = self.down1(x1)
-        x3 = self.down2(x2)
-        x4 = self.down3(x3)
-        x5 = self.down4(x4)
+        x2, x1 = self._down(self.down1, x1)
+        x3, x2 = self._down(self.down2, x2)
+        x4, x3 = self._down(self.down3, x3)
+        x5, x4 = self._down(self.down4, x4)
         return x1, x2, x3, x4, x5
 
     def _decode(self, x1, x2, x3, x4, x5):

@@ -243,7 +243,12 @@ def set_conv_precision(mode: str):
     """Arithmetic of the convolutions that have a split-bf16 kernel (15-row filters, stride 1): "f32" (default) or
     "bf16x3" -- every operand as hi + lo bf16 halves, products hi*hi + hi*lo + lo*hi accumulated in fp32.  The
     bf16x3 path agrees with the reference to ~2e-5 of a layer output's rms (inside the 1e-4 forward bound) but is
-    not bit-identical to the exact path; layers without a bf16x3 kernel keep the exact one."""
+    not bit-identical to the exact path; layers without a bf16x3 kernel keep the exact one.
+
+    Reproducibility: the exact path reduces every split sum in a fixed order (run-to-run bit-identical but for the
+    backward-data launches that add channel slices atomically at small batches); in this mode the weight-gradient GEMMs
+    of the linear / LSTM layers (`mpa_gemm_bf16x3`) additionally split K over workgroups that add into C atomically, so
+    two runs of the same step agree to rounding, not bit for bit."""
     if mode not in ("f32", "bf16x3"):
         raise ValueError(f"conv precision must be 'f32' or 'bf16x3', got {mode!r}")
     _Precision.conv = mode
@@ -351,7 +356,10 @@ class Conv2dFn(torch.autograd.Function):
             lib = _lib()
             xs, wpb = split_bf16(x), _packed_bfx(weight, d, 0)
             # the backward-weight kernel reads the split input: keep that instead of x (same number of bytes)
-            ctx.bfx_xs = bool(lib.mpa_conv2d_bf16x3_supported(ctypes.byref(d), 2))
+            # ... unless the backward-data pass of this geometry has no bf16x3 kernel (pw > kw - 1): it then runs on the exact
+            # kernel, which reads x
+            ctx.bfx_xs = bool(lib.mpa_conv2d_bf16x3_supported(ctypes.byref(d), 2)) and \
+                (not ctx.needs_input_grad[0] or bool(lib.mpa_conv2d_bf16x3_supported(ctypes.byref(d), 1)))
             ctx.save_for_backward(xs if ctx.bfx_xs else x, weight, y if act != ACT_NONE else None)
             partials = None
             if with_stats:
@@ -600,7 +608,7 @@ class BatchNormReLUFn(torch.autograd.Function):
         B, C, H, W = x.shape
         dx = torch.empty_like(x)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
-        ws = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+        ws = torch.empty(128 * C, dtype=torch.float64, device=x.device)       # (2 C for the SyncBN halves)
         if ctx.training and ctx.sync_world > 1:
             import torch.distributed as dist
             lib = _lib()
@@ -657,11 +665,94 @@ def max_pool2d(x, kernel, stride=None, padding=(0, 0)):
     return MaxPool2dFn.apply(x, tuple(kernel), tuple(stride), tuple(padding))
 
 
-class UpCatFn(torch.autograd.Function):
-    """unet_up_concat_padding.forward -- unet_cnns.py:93-104."""
+class PoolSkipFn(torch.autograd.Function):
+    """x -> (max_pool2d(x, k, s, p), x): an encoder level's output feeds the next level's MaxPool2d *and* the decoder's
+    unet_up_concat_padding (unet_cnns.py:562-571: x1 .. x4).  As one autograd node the two gradients meet here instead of
+    in autograd's accumulation (an ATen add kernel): the pool backward starts its LDS plane from the skip gradient -- read
+    in place from the first channels of the concatenated gradient (UpCatFn with skip_view) -- and writes their sum, one
+    pass instead of pool backward + slice copy + add."""
 
     @staticmethod
-    def forward(ctx, x1, x2):
+    def forward(ctx, x, k, s, p):
+        ctx.set_materialize_grads(False)
+        x = _c(x)
+        B, C, H, W = x.shape
+        OH = (H + 2 * p[0] - k[0]) // s[0] + 1
+        OW = (W + 2 * p[1] - k[1]) // s[1] + 1
+        if OH <= 0 or OW <= 0:
+            raise RuntimeError(f"max_pool2d: window {k} larger than input {(H, W)}")
+        y = torch.empty((B, C, OH, OW), dtype=torch.float32, device=x.device)
+        need = ctx.needs_input_grad[0]
+        idx = torch.empty((B, C, OH, OW), dtype=torch.int32, device=x.device) if need else None
+        _chk(_lib().mpa_maxpool2d_fwd(_p(x), _p(y), ctypes.c_void_p(idx.data_ptr()) if need else None, B, C, H, W,
+                                     k[0], k[1], s[0], s[1], p[0], p[1], _s()), "mpa_maxpool2d_fwd")
+        ctx.geom = (B, C, H, W, k, s, p)
+        ctx.save_for_backward(idx)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        B, C, H, W, k, s, p = ctx.geom
+        if dy is None:                                  # only the skip path was used
+            return dskip, None, None, None
+        (idx,) = ctx.saved_tensors
+        dy = _c(dy)
+        add, add_bs = None, 0
+        if dskip is not None:
+            if dskip.dtype != torch.float32 or not dskip.is_cuda or dskip.shape != (B, C, H, W):
+                raise RuntimeError("pool_skip: unexpected skip gradient")
+            st = dskip.stride()
+            if C * H * W == 0 or not (st[3] == 1 and st[2] == W and st[1] == H * W and st[0] >= C * H * W):
+                dskip = dskip.contiguous()              # (never on the models' path: UpCatFn hands a channel slice or a copy)
+                st = dskip.stride()
+            add, add_bs = dskip, st[0]
+        dx = torch.empty((B, C, H, W), dtype=torch.float32, device=dy.device)
+        _chk(_lib().mpa_maxpool2d_bwd_add(_p(dy), ctypes.c_void_p(idx.data_ptr()), _p(add), add_bs, _p(dx), B, C, H, W,
+                                         k[0], k[1], s[0], s[1], p[0], p[1], _s()), "mpa_maxpool2d_bwd_add")
+        return dx, None, None, None
+
+
+def pool_skip(x, kernel, stride=None, padding=(0, 0)):
+    """(max_pool2d(x), skip): `skip` is x for the decoder's upconcat; its gradient is consumed in place (see PoolSkipFn)"""
+    stride = kernel if stride is None else stride
+    y, skip = PoolSkipFn.apply(x, tuple(kernel), tuple(stride), tuple(padding))
+    skip._mpa_pool_skip = True              # upconcat(): hand the skip gradient over as a view of the concatenated one
+    return y, skip
+
+
+class FanoutFn(torch.autograd.Function):
+    """x -> (x, x) for a tensor with two consumers (the transformer layer's residual branches, unet_cnns.py:156-158; the CNN
+    family's residual stages): the two gradients are added by mpa_add here instead of by autograd's accumulation, which
+    would launch an ATen kernel."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None or gb is None:
+            return ga if gb is None else gb
+        ga, gb = _c(ga), _c(gb)
+        out = torch.empty_like(ga)
+        _chk(_lib().mpa_add(_p(ga), _p(gb), _p(out), ga.numel(), _s()), "mpa_add")
+        return out
+
+
+def fanout(x):
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return x, x
+    return FanoutFn.apply(x)
+
+
+class UpCatFn(torch.autograd.Function):
+    """unet_up_concat_padding.forward -- unet_cnns.py:93-104.  skip_view: x2 is PoolSkipFn's skip output, whose backward
+    reads its gradient in place -- the first Cs channels of dout -- so no copy of that half is made."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, skip_view=False):
+        ctx.skip_view = bool(skip_view)
         x1, x2 = _c(x1), _c(x2)
         B, C1, H1, W1 = x1.shape
         B2, Cs, Hs, Ws = x2.shape
@@ -677,13 +768,16 @@ class UpCatFn(torch.autograd.Function):
         B, C1, H1, W1, Cs, Hs, Ws = ctx.geom
         dout = _c(dout)
         dx1 = torch.empty((B, C1, H1, W1), dtype=torch.float32, device=dout.device)
+        if ctx.skip_view:
+            _chk(_lib().mpa_upcat_bwd(_p(dout), _p(dx1), None, B, C1, H1, W1, Cs, Hs, Ws, _s()), "mpa_upcat_bwd")
+            return dx1, dout[:, :Cs], None
         dskip = torch.empty((B, Cs, Hs, Ws), dtype=torch.float32, device=dout.device)
         _chk(_lib().mpa_upcat_bwd(_p(dout), _p(dx1), _p(dskip), B, C1, H1, W1, Cs, Hs, Ws, _s()), "mpa_upcat_bwd")
-        return dx1, dskip
+        return dx1, dskip, None
 
 
 def upconcat(x1, x2):
-    return UpCatFn.apply(x1, x2)
+    return UpCatFn.apply(x1, x2, bool(getattr(x2, "_mpa_pool_skip", False)))
 
 
 # --------------------------------------------------------------------------- pointwise

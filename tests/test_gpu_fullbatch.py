@@ -27,7 +27,8 @@ pytestmark = pytest.mark.gpu
 # AdamW's first steps move every weight by ~lr whatever its gradient: with the deterministic test fill (weights of one
 # scale in every layer) the scripts' 1e-3 / 2e-4 overshoot on a single repeated batch, 2e-5 descends for every family
 LR = 2e-5
-CASES = [("DRCNN:L", 64, 8), ("Unet:L", 128, 8), ("SAUnet:L", 256, 25), ("BLUnet:XXL", 256, 8), ("PUnet:XL", 128, 8)]
+# (PUnet:XL at 256: the batch SURVEY 8(d)'s FLOP table quotes for it -- 62.4 TFLOP per step)
+CASES = [("DRCNN:L", 64, 8), ("Unet:L", 128, 8), ("SAUnet:L", 256, 25), ("BLUnet:XXL", 256, 8), ("PUnet:XL", 256, 8)]
 
 
 @pytest.fixture(scope="module")
@@ -55,8 +56,17 @@ def _train(dev, name, B, use_graph, steps=3):
     return model, ts, losses, x
 
 
+@pytest.fixture(params=["f32", "bf16x3"])
+def precision(request):
+    """both arithmetics of the convolutions / large GEMMs (ops.set_conv_precision): the exact fp32 default and the opt-in
+    split-bf16 mode, each at the BASELINE batch"""
+    ops.set_conv_precision(request.param)
+    yield request.param
+    ops.set_conv_precision("f32")
+
+
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[0]}-B{c[1]}")
-def test_whole_model_at_baseline_batch(dev, case):
+def test_whole_model_at_baseline_batch(dev, case, precision):
     name, B, n_eval = case
     _, _, l_eager, _ = _train(dev, name, B, use_graph=False)
     torch.cuda.empty_cache()

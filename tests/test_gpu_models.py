@@ -34,7 +34,10 @@ def dev():
 def conv_precision(request):
     """every test of this file runs twice: with the exact-fp32 convolutions (default) and with the opt-in split-bf16
     path (ops.set_conv_precision("bf16x3"): the 15-row filters as hi/lo bf16 halves, three MFMAs per product, fp32
-    accumulation) -- same goldens, same tolerances"""
+    accumulation) -- same goldens.  Forward bounds are the same (1e-4, equal argmax); the *gradient* bounds of the bf16x3
+    mode are looser (TOL below: the bf16 MFMA truncates its accumulation, which biases gradients that cancel -- measured in
+    profiles/r03_bf16x3_grad_diag.txt), so these model-level checks are not what pins the bf16x3 kernels' indexing: the
+    operator-level tests against float64 in tests/test_gpu_bf16x3.py are (<= 1e-5 relative L2 on all three passes)."""
     from multipitch_architectures_amd import ops
     ops.set_conv_precision(request.param)
     yield request.param
