@@ -288,11 +288,11 @@ int mpa_lstm_cell_bwd(const float* dh, int64_t dh_stride, const float* dh_rec /*
                       float* dc_prev, int B, int H, void* stream);
 
 /* ------------------------------------------------------------------ losses (caller side, exp126a...py:87; exp195f...py:331-334)
- * BCELoss(mean) on probabilities with the -100 clamp; loss_out[0] += sum / n (zero it first).               */
+ * BCELoss(mean) on probabilities with the -100 clamp; loss_out[0] = sum / n (zeroed by the call).                 */
 int mpa_bce_fwd(const float* p, const float* y, float* loss_out, int64_t n, void* stream);
 /* dp = g[0] * d(mean BCE)/dp ; g is a device scalar (the upstream gradient), nullable = 1 */
 int mpa_bce_bwd(const float* p, const float* y, float* dp, int64_t n, const float* g, void* stream);
-/* CrossEntropyLoss(mean) over rows of (B,K) logits with int64 targets; loss_out[0] += scale*mean.            */
+/* CrossEntropyLoss(mean) over rows of (B,K) logits with int64 targets; loss_out[0] = scale*mean (zeroed by the call). */
 int mpa_ce_fwd_bwd(const float* logits, const int64_t* target, float* loss_out, float* dlogits, int B, int K,
                    float scale, void* stream);
 

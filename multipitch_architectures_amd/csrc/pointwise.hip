@@ -759,6 +759,7 @@ int mpa_add_rows_bcast(const float* x, const float* pe, float* y, int B, int64_t
 
 int mpa_bce_fwd(const float* p, const float* y, float* loss_out, int64_t n, void* stream) {
   if (!p || !y || !loss_out || n <= 0) return MPA_ERR_ARG;
+  if (mpa_zero_async(loss_out, sizeof(float), (hipStream_t)stream) != MPA_OK) return MPA_ERR_LAUNCH;   // the blocks add into it
   MPA_LAUNCH(bce_fwd_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, y, loss_out, (long)n,
                      1.0f / (float)n);
   return mpa_launch_status();
@@ -772,6 +773,7 @@ int mpa_bce_bwd(const float* p, const float* y, float* dp, int64_t n, const floa
 int mpa_ce_fwd_bwd(const float* logits, const int64_t* target, float* loss_out, float* dlogits, int B, int K, float scale,
                    void* stream) {
   if (!logits || !target || !loss_out || B <= 0) return MPA_ERR_ARG;
+  if (mpa_zero_async(loss_out, sizeof(float), (hipStream_t)stream) != MPA_OK) return MPA_ERR_LAUNCH;   // the rows add into it
   MPA_LAUNCH(ce_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, logits, target, loss_out, dlogits, B, K, scale);
   return mpa_launch_status();
 }

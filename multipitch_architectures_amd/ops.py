@@ -85,6 +85,21 @@ def _rng_state(device):
     return st
 
 
+_seed_ones = {}
+
+
+def backward_seed(loss):
+    """d loss / d loss = 1 as a persistent tensor: `loss.backward(ops.backward_seed(loss))` spares the ones_like fill kernel
+    autograd launches for a bare `loss.backward()` (the last ATen kernel of a training step)."""
+    key = (loss.device, loss.dtype, tuple(loss.shape))
+    t = _seed_ones.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the backward seed must exist before a HIP graph is captured: run one eager step first")
+        t = _seed_ones[key] = torch.ones(loss.shape, dtype=loss.dtype, device=loss.device)
+    return t
+
+
 def rng_advance():
     """End of a training step: move the device-side base of the dropout stream past everything the step drew.  One tiny
     kernel; inside a captured graph it is what makes every replay use new random numbers."""
@@ -1293,7 +1308,7 @@ class BCELossFn(torch.autograd.Function):
         if p.shape != y.shape:
             raise ValueError(f"Using a target size ({tuple(y.shape)}) that is different to the input size "
                              f"({tuple(p.shape)}) is deprecated. Please ensure they have the same size.")
-        loss = torch.zeros((), dtype=torch.float32, device=p.device)
+        loss = torch.empty((), dtype=torch.float32, device=p.device)       # (zeroed by the call: no ATen fill kernel)
         _chk(_lib().mpa_bce_fwd(_p(p), _p(y), _p(loss), p.numel(), _s()), "mpa_bce_fwd")
         ctx.save_for_backward(p, y)
         return loss
@@ -1316,7 +1331,7 @@ class CrossEntropyFn(torch.autograd.Function):
         if logits.numel() != B * K:
             raise RuntimeError("cross_entropy: only (B,K,1,1) logits are supported")
         target = target.reshape(B).to(torch.int64).contiguous()
-        loss = torch.zeros((), dtype=torch.float32, device=logits.device)
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)  # (zeroed by the call)
         dl = torch.empty_like(logits)
         _chk(_lib().mpa_ce_fwd_bwd(_p(logits), ctypes.c_void_p(target.data_ptr()), _p(loss), _p(dl), B, K, float(scale),
                                   _s()), "mpa_ce_fwd_bwd")

@@ -75,7 +75,7 @@ class TrainStep:
         ops.begin_pack_window()
         loss = self.criterion(self.model(x), y)
         self.opt.zero_grad()
-        loss.backward()
+        loss.backward(ops.backward_seed(loss))
         return loss
 
     def _update(self):

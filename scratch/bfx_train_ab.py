@@ -12,18 +12,21 @@ from run_experiment import synthetic_recording
 EPOCHS = int(os.environ.get("AB_EPOCHS", "12")); NREC = int(os.environ.get("AB_RECORDINGS", "6")); FRAMES = int(os.environ.get("AB_FRAMES", "1500"))
 
 
-def run(config, precision):
+def run(config, precision, seed=1234):
     ops.set_conv_precision(precision)
-    ops.manual_seed(1234)
+    ops.manual_seed(seed)                 # dropout stream; weights, data and batch order are the same in every run
     torch.manual_seed(0)
     model, criterion, cfg = experiment.build(config)
     train_files = [synthetic_recording(FRAMES, 100 + k) for k in range(NREC)]
     val_files, test_files = [synthetic_recording(FRAMES, 7)], [synthetic_recording(FRAMES // 2, 8)]
     t0 = time.time()
-    hist = experiment.train(model, criterion, train_files, val_files, lr=cfg["lr"], max_epochs=EPOCHS, log=lambda *_: None)
+    ckpt = os.path.join("/tmp", f"ab_{config.replace(':', '_')}_{precision}_{seed}.pt")
+    hist = experiment.train(model, criterion, train_files, val_files, lr=cfg["lr"], max_epochs=EPOCHS, log=lambda *_: None,
+                            path_trained_model=ckpt)
+    model.load_state_dict(torch.load(ckpt))          # the best-validation model, as the scripts test it (exp126a...py:383-391)
     mean, _ = experiment.test(model, test_files, ["synthetic-test"], log=lambda *_: None)
     ops.set_conv_precision("f32")
-    return {"precision": precision, "epochs": len(hist), "train_loss": [h[0] for h in hist], "val_loss": [h[1] for h in hist],
+    return {"precision": precision, "dropout_seed": seed, "epochs": len(hist), "train_loss": [h[0] for h in hist], "val_loss": [h[1] for h in hist],
             "test": {k: float(v) for k, v in mean.items()}, "seconds": time.time() - t0}
 
 
@@ -32,10 +35,13 @@ if __name__ == "__main__":
     out = {"task": f"experiments/run_experiment.py --synthetic {NREC} --frames {FRAMES} --epochs {EPOCHS}", "runs": {}}
     for config in (sys.argv[1:] or ["tiny:SAUnet", "tiny:DRCNN"]):
         a, b = run(config, "f32"), run(config, "bf16x3")
-        out["runs"][config] = {"f32": a, "bf16x3": b,
-                               "final_val_loss_diff": abs(a["val_loss"][-1] - b["val_loss"][-1]),
-                               "f_measure_diff_pp": 100.0 * abs(a["test"]["f_measure"] - b["test"]["f_measure"])}
-        print(config, "f32 val", [round(v, 4) for v in a["val_loss"]], "F", round(a["test"]["f_measure"], 4))
-        print(config, "bfx val", [round(v, 4) for v in b["val_loss"]], "F", round(b["test"]["f_measure"], 4), flush=True)
+        a2, b2 = run(config, "f32", seed=4321), run(config, "bf16x3", seed=4321)     # the noise floor: another dropout stream
+        F = lambda r: r["test"]["f_measure"]
+        out["runs"][config] = {"f32": a, "bf16x3": b, "f32_other_dropout_seed": a2, "bf16x3_other_dropout_seed": b2,
+                               "best_val_loss": {"f32": min(a["val_loss"]), "bf16x3": min(b["val_loss"])},
+                               "f_measure_diff_pp": 100.0 * abs(F(a) - F(b)),
+                               "f_measure_seed_spread_pp": 100.0 * max(abs(F(a) - F(a2)), abs(F(b) - F(b2)))}
+        print(config, "F f32", round(F(a), 4), round(F(a2), 4), "bf16x3", round(F(b), 4), round(F(b2), 4),
+              "best val", round(min(a["val_loss"]), 4), round(min(b["val_loss"]), 4), "epochs", a["epochs"], b["epochs"], flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r04_bf16x3_train_ab.json"), "w"), indent=1)

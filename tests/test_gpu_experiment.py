@@ -135,3 +135,45 @@ def test_file_evaluation_matches_the_oracle_chain(name):
         assert got[m] == pytest.approx(want[m], abs=1e-12), m
     for m in MEASURES:
         assert got[m] == pytest.approx(want[m], rel=2e-4, abs=1e-6), m
+
+
+@pytest.mark.parametrize("config", ["tiny:SAUnet", "tiny:Unet"])
+def test_bf16x3_training_reaches_the_f_measure_of_exact_fp32(config, tmp_path):
+    """A/B of a real (small) training run in the two arithmetics (BASELINE.json configs[1] / [4] name reduced precision; the
+    mode is opt-in here): the runner's synthetic task, same weights, data and batch order, best-validation checkpoint tested
+    with the scripts' flow (threshold 0.4).  The task is small and its outcome depends on the dropout stream by several
+    points of F-measure, so the bar is taken against that noise: over two dropout seeds, the split-bf16 runs must reach the
+    exact runs' mean F-measure to within 1 pp + the seed-to-seed spread of the exact runs, and both must have learnt the
+    task.  (The trajectories of one such A/B: profiles/r04_bf16x3_train_ab.json, scratch/bfx_train_ab.py.)"""
+    import importlib.util
+    import os
+    from multipitch_architectures_amd import experiment, ops
+    spec = importlib.util.spec_from_file_location(
+        "run_experiment", os.path.join(os.path.dirname(os.path.dirname(__file__)), "experiments", "run_experiment.py"))
+    run = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(run)
+    train_files = [run.synthetic_recording(3000, 100 + k) for k in range(12)]
+    val_files, test_files = [run.synthetic_recording(3000, 7)], [run.synthetic_recording(1500, 8)]
+
+    def one(precision, seed):
+        ops.set_conv_precision(precision)
+        try:
+            ops.manual_seed(seed)
+            torch.manual_seed(0)
+            model, criterion, cfg = experiment.build(config)
+            ckpt = str(tmp_path / f"{precision}_{seed}.pt")
+            hist = experiment.train(model, criterion, train_files, val_files, lr=cfg["lr"], max_epochs=60, path_trained_model=ckpt,
+                                    log=lambda *_: None)
+            model.load_state_dict(torch.load(ckpt))
+            mean, _ = experiment.test(model, test_files, ["synthetic"], log=lambda *_: None)
+        finally:
+            ops.set_conv_precision("f32")
+        return float(mean["f_measure"]), min(h[1] for h in hist)
+
+    exact = [one("f32", s) for s in (1234, 4321)]
+    split = [one("bf16x3", s) for s in (1234, 4321)]
+    f_exact, f_split = [f for f, _ in exact], [f for f, _ in split]
+    assert min(f_exact) > 0.6 and min(f_split) > 0.6, (exact, split)                 # every run learnt the task
+    spread = abs(f_exact[0] - f_exact[1])
+    assert np.mean(f_split) >= np.mean(f_exact) - (0.01 + spread), (exact, split)
+    assert min(v for _, v in split) <= 2.0 * min(v for _, v in exact), (exact, split)  # best validation loss: same league
