@@ -192,6 +192,12 @@ int mpa_maxpool2d_bwd_add(const float* dy, const int32_t* idx, const float* add 
 /* unet_up_concat_padding (unet_cnns.py:93-104): out = cat([skip, pad(bilinear_x2_align_corners(x1))], dim=1) */
 int mpa_upcat_fwd(const float* x1, const float* skip, float* out, int B, int C1, int H1, int W1, int Cs, int Hs,
                   int Ws, void* stream);
+/* the same with upsampling factors (fh, fw) <= 4 instead of (2, 2): unet_up_concat_padding((2,3)) of the temporal U-Nets
+ * (unet_cnns.py:1185, 1326); (2, 2) takes the kernels above */
+int mpa_upcat_scaled_fwd(const float* x1, const float* skip, float* out, int B, int C1, int H1, int W1, int Cs, int Hs,
+                         int Ws, int fh, int fw, void* stream);
+int mpa_upcat_scaled_bwd(const float* dout, float* dx1, float* dskip /*nullable*/, int B, int C1, int H1, int W1, int Cs,
+                         int Hs, int Ws, int fh, int fw, void* stream);
 /* dskip == NULL: only dx1 is formed (the caller reads the skip half dout[:, :Cs] in place, mpa_maxpool2d_bwd_add) */
 int mpa_upcat_bwd(const float* dout, float* dx1, float* dskip /*nullable*/, int B, int C1, int H1, int W1, int Cs, int Hs,
                   int Ws, void* stream);

@@ -91,6 +91,8 @@ SIGNATURES = {
     "mpa_maxpool2d_bwd_add": (c_int, [_P, _P, _P, c_int64, _P] + [c_int] * 10 + [_P]),
     "mpa_upcat_fwd": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P]),
     "mpa_upcat_bwd": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P]),
+    "mpa_upcat_scaled_fwd": (c_int, [_P, _P, _P] + [c_int] * 9 + [_P]),
+    "mpa_upcat_scaled_bwd": (c_int, [_P, _P, _P] + [c_int] * 9 + [_P]),
     "mpa_logsoftmax_cat_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "mpa_logsoftmax_cat_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "mpa_act_fwd": (c_int, [_P, _P, c_int64, c_int, c_float, _P]),

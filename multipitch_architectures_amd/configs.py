@@ -101,6 +101,17 @@ VARIANT_CONFIGS = {
     "simple_u_net_polyphony_classif": dict(_VT, num_polyphony_steps=24),
     "simple_u_net_doubleselfattn_polyphony": dict(_VT, **_VA),
     "simple_u_net_doubleselfattn_polyphony_classif": dict(_VT, **_VA, num_polyphony_steps=24),
+    # time_embed_dim = 72 bins x n_chan_layers[1]; n_chan_layers[1] == n_chan_layers[2] (the class runs with nothing else)
+    # (16 heads: the head dimension of the time layers, 288 / 16 = 18, has to stay within the attention kernels' 32)
+    "simple_u_net_doubleselfattn_transenc": dict(n_chan_layers=[8, 4, 4, 2], n_bins_out=72, scalefac=16, embed_dim=32,
+                                                 num_heads=16, mlp_dim=24, self_attn_depth=1, self_attn_number=1,
+                                                 time_embed_dim=288, pos_encoding="sinusoidal"),
+    # scalefac 16: channels 1 / 3 / 9 / 27 / 108, channels x bins = 216 on every level = embed_dim (8 heads of 27)
+    "u_net_temporal_selfattn_varlayers": dict(n_chan_layers=[8, 6, 5, 4], n_bins_out=72, scalefac=16, embed_dim=216,
+                                              num_heads=8, mlp_dim=24, self_attn_depth=2, self_attn_number=2,
+                                              pos_encoding="sinusoidal"),
+    "u_net_temporal_blstm_varlayers": dict(n_chan_layers=[8, 6, 5, 4], n_bins_out=72, scalefac=16, embed_dim=216,
+                                           hidden_size=108, lstm_depth=2, lstm_number=1),
     "basic_cnn": dict(n_chan_layers=[8, 6, 5, 4], n_bins_out=72),
     "basic_cnn_pool": dict(n_chan_layers=[8, 6, 5, 4], n_bins_out=72),
     "basic_cnn_segm_logsoftmax": dict(n_chan_layers=[8, 6, 5, 4], n_ch_out=3, n_bins_out=72),

@@ -267,12 +267,14 @@ __device__ __forceinline__ void bilin_src(int dst, int n_in, int n_out, int& i0,
 }
 
 // one wave per output row (b, c, y)
+// (fh, fw): the upsampling factors -- (2,2) everywhere in the experiments' models; (2,3) in the temporal U-Nets
+// (unet_cnns.py:1185), which only this generic kernel and upcat_bwd_kernel serve
 __global__ __launch_bounds__(256) void upcat_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ skip,
                                                         float* __restrict__ out, int B, int C1, int H1, int W1, int Cs,
-                                                        int Hs, int Ws) {
+                                                        int Hs, int Ws, int fh, int fw) {
   const int Ct = Cs + C1;
   const long rows = (long)B * Ct * Hs;
-  const int UH = 2 * H1, UW = 2 * W1;
+  const int UH = fh * H1, UW = fw * W1;
   const int padT = (Hs - UH) / 2, padL = (Ws - UW) / 2;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
@@ -454,9 +456,9 @@ __global__ __launch_bounds__(256) void upcat_bwd_flat_kernel(const float* __rest
 // B*Cs*Hs skip rows, then the B*C1*H1 rows of dx1.
 __global__ __launch_bounds__(256) void upcat_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx1,
                                                         float* __restrict__ dskip, int B, int C1, int H1, int W1, int Cs,
-                                                        int Hs, int Ws, long row0) {
+                                                        int Hs, int Ws, long row0, int fh, int fw) {
   const int Ct = Cs + C1;
-  const int UH = 2 * H1, UW = 2 * W1;
+  const int UH = fh * H1, UW = fw * W1;
   const int padT = (Hs - UH) / 2, padL = (Ws - UW) / 2;
   const long rskip = (long)B * Cs * Hs, rx1 = (long)B * C1 * H1;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -475,10 +477,10 @@ __global__ __launch_bounds__(256) void upcat_bwd_kernel(const float* __restrict_
     const int c = (int)(bc - (long)b * C1);
     const float* dp = dout + (((long)b * Ct + Cs + c) * Hs) * Ws;
     // rows of the upsampled image that read source row ii, with their weights (wave-uniform)
-    float wys[6];
-    int oys[6];
+    float wys[10];                       // at most 2 fh + 1 rows read one source row (fh <= 4)
+    int oys[10];
     int nwy = 0;
-    const int uy_lo = max(0, 2 * ii - 2), uy_hi = min(UH - 1, 2 * ii + 3);
+    const int uy_lo = max(0, fh * ii - fh - 1), uy_hi = min(UH - 1, fh * ii + 2 * fh);
     for (int uy = uy_lo; uy <= uy_hi; ++uy) {
       int y0, y1;
       float ly;
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(256) void upcat_bwd_kernel(const float* __restrict_
     }
     for (int j = lane; j < W1; j += 64) {
       float s = 0.f;
-      const int ux_lo = max(0, 2 * j - 2), ux_hi = min(UW - 1, 2 * j + 3);
+      const int ux_lo = max(0, fw * j - fw - 1), ux_hi = min(UW - 1, fw * j + 2 * fw);
       for (int ux = ux_lo; ux <= ux_hi; ++ux) {
         int x0, x1i;
         float lx;
@@ -685,7 +687,27 @@ int mpa_upcat_fwd(const float* x1, const float* skip, float* out, int B, int C1,
     return mpa_launch_status();
   }
   MPA_LAUNCH(upcat_fwd_kernel, dim3(row_blocks((long)B * (Cs + C1) * Hs)), dim3(256), 0, (hipStream_t)stream, x1,
-                     skip, out, B, C1, H1, W1, Cs, Hs, Ws);
+                     skip, out, B, C1, H1, W1, Cs, Hs, Ws, 2, 2);
+  return mpa_launch_status();
+}
+
+int mpa_upcat_scaled_fwd(const float* x1, const float* skip, float* out, int B, int C1, int H1, int W1, int Cs, int Hs, int Ws,
+                         int fh, int fw, void* stream) {
+  if (fh == 2 && fw == 2) return mpa_upcat_fwd(x1, skip, out, B, C1, H1, W1, Cs, Hs, Ws, stream);
+  if (!x1 || !skip || !out || fh < 1 || fw < 1 || fh > 4 || fw > 4 || Hs < fh * H1 || Ws < fw * W1) return MPA_ERR_ARG;
+  MPA_LAUNCH(upcat_fwd_kernel, dim3(row_blocks((long)B * (Cs + C1) * Hs)), dim3(256), 0, (hipStream_t)stream, x1,
+                     skip, out, B, C1, H1, W1, Cs, Hs, Ws, fh, fw);
+  return mpa_launch_status();
+}
+
+int mpa_upcat_scaled_bwd(const float* dout, float* dx1, float* dskip, int B, int C1, int H1, int W1, int Cs, int Hs, int Ws,
+                         int fh, int fw, void* stream) {
+  if (fh == 2 && fw == 2) return mpa_upcat_bwd(dout, dx1, dskip, B, C1, H1, W1, Cs, Hs, Ws, stream);
+  if (!dout || !dx1 || fh < 1 || fw < 1 || fh > 4 || fw > 4) return MPA_ERR_ARG;
+  const long rskip = (long)B * Cs * Hs, rx1 = (long)B * C1 * H1;
+  const long row0 = dskip ? 0L : rskip;
+  MPA_LAUNCH(upcat_bwd_kernel, dim3(row_blocks(rskip + rx1 - row0)), dim3(256), 0, (hipStream_t)stream, dout, dx1, dskip, B, C1,
+             H1, W1, Cs, Hs, Ws, row0, fh, fw);
   return mpa_launch_status();
 }
 
@@ -704,7 +726,7 @@ int mpa_upcat_bwd(const float* dout, float* dx1, float* dskip, int B, int C1, in
                  Hs, Ws);
     else
       MPA_LAUNCH(upcat_bwd_kernel, dim3(row_blocks(rx10)), dim3(256), 0, (hipStream_t)stream, dout, dx1, dskip, B, C1, H1, W1,
-                 Cs, Hs, Ws, rskip0);
+                 Cs, Hs, Ws, rskip0, 2, 2);
     return mpa_launch_status();
   }
   if (((long)Cs * Hs * Ws) % 4 == 0 && ((long)(Cs + C1) * Hs * Ws) % 4 == 0) {
@@ -724,12 +746,12 @@ int mpa_upcat_bwd(const float* dout, float* dx1, float* dskip, int B, int C1, in
                  Hs, Ws);
     else
       MPA_LAUNCH(upcat_bwd_kernel, dim3(row_blocks(rx1)), dim3(256), 0, (hipStream_t)stream, dout, dx1, dskip, B, C1, H1, W1,
-                 Cs, Hs, Ws, rskip);
+                 Cs, Hs, Ws, rskip, 2, 2);
     return mpa_launch_status();
   }
   const long n = (long)B * Cs * Hs + (long)B * C1 * H1;
   MPA_LAUNCH(upcat_bwd_kernel, dim3(row_blocks(n)), dim3(256), 0, (hipStream_t)stream, dout, dx1, dskip, B, C1, H1, W1,
-                     Cs, Hs, Ws, 0L);
+                     Cs, Hs, Ws, 0L, 2, 2);
   return mpa_launch_status();
 }
 

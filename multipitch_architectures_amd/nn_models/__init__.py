@@ -12,10 +12,12 @@ from .basic_cnns import (basic_cnn, basic_cnn_pool, basic_cnn_segm_blank_logsoft
                          deep_cnn_segm_sigmoid)
 from .unet_cnns import (blstm_temporal_enc_layer, double_conv, simple_u_net, simple_u_net_doubleselfattn,
                         simple_u_net_doubleselfattn_alllayers, simple_u_net_doubleselfattn_polyphony,
-                        simple_u_net_doubleselfattn_polyphony_classif, simple_u_net_doubleselfattn_twolayers,
+                        simple_u_net_doubleselfattn_polyphony_classif, simple_u_net_doubleselfattn_transenc,
+                        simple_u_net_doubleselfattn_twolayers,
                         simple_u_net_doubleselfattn_varlayers, simple_u_net_largekernels, simple_u_net_polyphony_classif,
                         simple_u_net_polyphony_classif_softmax, simple_u_net_selfattn, simple_u_net_sixselfattn,
-                        transformer_enc_layer, u_net_blstm_varlayers, unet_up_concat_padding)
+                        transformer_enc_layer, transformer_temporal_enc_layer, u_net_blstm_varlayers,
+                        u_net_temporal_blstm_varlayers, u_net_temporal_selfattn_varlayers, unet_up_concat_padding)
 
 BUILT = ["basic_cnn_segm_sigmoid", "deep_cnn_segm_sigmoid", "double_conv", "unet_up_concat_padding",
          "transformer_enc_layer", "blstm_temporal_enc_layer", "simple_u_net_largekernels",
@@ -25,11 +27,14 @@ BUILT = ["basic_cnn_segm_sigmoid", "deep_cnn_segm_sigmoid", "double_conv", "unet
          "simple_u_net", "simple_u_net_selfattn", "simple_u_net_sixselfattn", "simple_u_net_doubleselfattn_alllayers",
          "simple_u_net_doubleselfattn_varlayers", "simple_u_net_polyphony_classif",
          "simple_u_net_doubleselfattn_polyphony", "simple_u_net_doubleselfattn_polyphony_classif", "basic_cnn_pool",
-         "basic_cnn_segm_logsoftmax", "basic_cnn_segm_blank_logsoftmax", "basic_cnn"]
+         "basic_cnn_segm_logsoftmax", "basic_cnn_segm_blank_logsoftmax", "basic_cnn",
+         # round 4: the time-axis transformer layer and the U-Net that reduces time with it
+         "transformer_temporal_enc_layer", "simple_u_net_doubleselfattn_transenc",
+         # ... and the U-Nets with (2,3) pooling / upsampling and time-axis transformer / BiLSTM layers on their skips
+         "u_net_temporal_selfattn_varlayers", "u_net_temporal_blstm_varlayers"]
 
 NOT_BUILT = ["single_conv", "freq_u_net", "freq_u_net_bottomstack",
-             "freq_u_net_selfattn", "freq_u_net_doubleselfattn", "u_net_temporal_selfattn_varlayers",
-             "transformer_temporal_enc_layer", "simple_u_net_doubleselfattn_transenc", "u_net_temporal_blstm_varlayers"]
+             "freq_u_net_selfattn", "freq_u_net_doubleselfattn"]
 
 
 def _not_built(name):

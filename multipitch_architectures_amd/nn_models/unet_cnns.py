@@ -10,7 +10,7 @@ import torch.nn as nn
 from .. import ops
 from .basic_cnns import _head
 from .layers import (BatchNorm2d, Conv2d, ConvActPoolDrop, Dropout, ELU, LayerNorm, LeakyReLU, Linear, LSTM, MaxPool2d,
-                     MultiheadAttention, ReLU)
+                     MultiheadAttention, ReLU, Sigmoid)
 
 
 class _DoubleConvSeq(nn.Sequential):
@@ -91,12 +91,12 @@ class unet_up_concat_padding(nn.Module):
 
     def __init__(self, upsamp_fac=(2, 2), bilinear=True):
         super().__init__()
-        if tuple(upsamp_fac) != (2, 2):
-            raise NotImplementedError("only the (2,2) bilinear upsampling the reference's models use is built")
-        self.upsamp_fac = tuple(upsamp_fac)
+        self.upsamp_fac = tuple(int(f) for f in upsamp_fac)
+        if len(self.upsamp_fac) != 2 or not all(1 <= f <= 4 for f in self.upsamp_fac):
+            raise NotImplementedError("bilinear upsampling factors 1..4 per axis are built ((2,2), and (2,3) of the temporal U-Nets)")
 
     def forward(self, x1, x2):
-        return ops.upconcat(x1, x2)
+        return ops.upconcat(x1, x2, self.upsamp_fac)
 
 
 def _sinusoidal_pe(max_len, embed_dim):
@@ -113,11 +113,13 @@ class transformer_enc_layer(nn.Module):
     """ Transformer encoder layer, with multi-head self-attention and fully connected network (MLP)
     (unet_cnns.py:107-159).  The attention runs over the batch axis, as in the reference (Appendix C.1)."""
 
+    MAX_LEN = 600
+
     def __init__(self, embed_dim=32, num_heads=8, mlp_dim=512, p_dropout=0.2, pos_encoding=None):
         super().__init__()
         self.embed_dim = embed_dim
         self.pos_encoding = pos_encoding
-        max_len = 600
+        max_len = self.MAX_LEN
         if pos_encoding == 'sinusoidal':
             self.pe = _sinusoidal_pe(max_len, embed_dim)          # plain attribute, not in state_dict (Appendix C.3)
             self.dropout_pe = Dropout(p=p_dropout)
@@ -152,12 +154,18 @@ class transformer_enc_layer(nn.Module):
         if E != self.embed_dim:
             raise RuntimeError(f"transformer_enc_layer: expected {self.embed_dim} channels, got {E}")
         xf = x.reshape(B, E, S)                                  # view
+        return ops.transpose_last2(self._encode_tokens(self._tokens(xf))).reshape(B, E, H, W)
+
+    def _tokens(self, xf):
+        """(B,E,S) -> (B,S,E) tokens, with the positional table added (and its dropout) when the layer has one"""
         if self.pos_encoding is not None:
-            if S > self.pe.shape[0]:
-                raise RuntimeError(f"sequence of {S} positions exceeds the positional table ({self.pe.shape[0]})")
-            t = self.dropout_pe(ops.transpose_last2(xf, self._pe_on(x.device)))
-        else:
-            t = ops.transpose_last2(xf)                          # (B,S,E)
+            if xf.shape[2] > self.pe.shape[0]:
+                raise RuntimeError(f"sequence of {xf.shape[2]} positions exceeds the positional table ({self.pe.shape[0]})")
+            return self.dropout_pe(ops.transpose_last2(xf, self._pe_on(xf.device)))
+        return ops.transpose_last2(xf)
+
+    def _encode_tokens(self, t):
+        """the encoder layer proper on (B,S,E) tokens: attention over the batch axis + MLP, post-norm (unet_cnns.py:153-158)"""
         # t and x1_norm each feed a projection and a residual branch: explicit fan-outs, so that their two gradients are
         # added by an in-tree kernel (ops.fanout) instead of by autograd's accumulation
         t, t_res = ops.fanout(t)
@@ -166,8 +174,30 @@ class transformer_enc_layer(nn.Module):
         x1_proj = self.o_linear(x1)
         x1_norm, x1_res = ops.fanout(self.layernorm1(t_res, self.dropout1(x1_proj)))
         x2 = self.mlp[2](self.mlp[0](x1_norm, ops.ACT_RELU))
-        x2_norm = self.layernorm2(x1_res, self.dropout2(x2))
-        return ops.transpose_last2(x2_norm).reshape(B, E, H, W)
+        return self.layernorm2(x1_res, self.dropout2(x2))
+
+
+class transformer_temporal_enc_layer(transformer_enc_layer):
+    """ Transformer encoder layer only over time dimension (unet_cnns.py:162-217): the tokens are the T' time frames, their
+    features the channels x frequency bins (C*F' == embed_dim).  As in transformer_enc_layer the (B,T',E) tokens go to an
+    nn.MultiheadAttention with batch_first=False, so the attention still runs over the batch axis (Appendix C.1).  Same
+    parameters and state_dict keys as transformer_enc_layer; positional table of 174 rows."""
+    MAX_LEN = 174
+
+    def __init__(self, embed_dim=32, num_heads=8, mlp_dim=512, p_dropout=0.2, pos_encoding=None):
+        super().__init__(embed_dim=embed_dim, num_heads=num_heads, mlp_dim=mlp_dim, p_dropout=p_dropout,
+                         pos_encoding=pos_encoding)
+        self.flatten = nn.Flatten(start_dim=-3, end_dim=-2)      # (attribute of the reference; no parameters)
+
+    def forward(self, x):
+        B, C, T, Fq = x.shape
+        if C * Fq != self.embed_dim:
+            raise RuntimeError(f"transformer_temporal_enc_layer: needs C*F' == embed_dim, got {C}*{Fq} vs {self.embed_dim}")
+        # x.transpose(2,3) -> flatten(C,F') -> (B, C*F', T): feature index c*F' + f, as blstm_temporal_enc_layer
+        xt = ops.transpose_last2(x.reshape(B * C, T, Fq)).reshape(B, C * Fq, T)
+        out = self._encode_tokens(self._tokens(xt))                # (B,T,C*F')
+        y = ops.transpose_last2(out).reshape(B * C, Fq, T)
+        return ops.transpose_last2(y).reshape(B, C, T, Fq)
 
 
 class blstm_temporal_enc_layer(nn.Module):
@@ -214,7 +244,7 @@ class _UNetTrunk(nn.Module):
         self.down4 = nn.Sequential(MaxPool2d((2, 2)), double_conv(in_channels=512 // sc, out_channels=1024 // (sc * 2), mid_channels=1024 // (sc * 2), **kp(ks[4]), **kw))
 
     def _build_decoder(self, n_ch, n_bins_in, n_bins_out, a_lrelu, p_dropout, sc, convdrop=0, residual=False,
-                       alt_order=False, ks=LARGE):
+                       alt_order=False, ks=LARGE, head=True):
         kw = dict(convdrop=convdrop, residual=residual, alt_order=alt_order)
         kp = lambda k: dict(kernel_size=(k, k), padding=(k // 2, k // 2))
         self.upconcat = unet_up_concat_padding((2, 2))
@@ -222,7 +252,10 @@ class _UNetTrunk(nn.Module):
         self.upconv2 = double_conv(in_channels=512 // sc, out_channels=256 // (sc * 2), mid_channels=512 // (sc * 2), **kp(ks[3]), **kw)
         self.upconv3 = double_conv(in_channels=256 // sc, out_channels=128 // (sc * 2), mid_channels=256 // (sc * 2), **kp(ks[2]), **kw)
         self.upconv4 = double_conv(in_channels=128 // sc, out_channels=n_ch[0], mid_channels=128 // (sc * 2), **kp(ks[0]), **kw)
-        self.conv2, self.conv3, self.conv4 = _head(n_ch[0], n_ch, n_bins_in, n_bins_out, a_lrelu, p_dropout)
+        if head:
+            self.conv2, self.conv3, self.conv4 = _head(n_ch[0], n_ch, n_bins_in, n_bins_out, a_lrelu, p_dropout)
+        else:
+            self.conv2 = _head(n_ch[0], n_ch, n_bins_in, n_bins_out, a_lrelu, p_dropout)[0]
 
     @staticmethod
     def _down(stage, x):
@@ -481,6 +514,161 @@ class simple_u_net_doubleselfattn_varlayers(_UNetTrunk):
         x1 = self._attend(x1, 1, 4)
         x = self.upconv4(self.upconcat(x, x1))
         return self.conv4(self.conv3(self.conv2(x)))
+
+
+class simple_u_net_doubleselfattn_transenc(simple_u_net_doubleselfattn_varlayers):
+    """unet_cnns.py:1370-1521: the _varlayers U-Net (its skip / bottleneck transformer layers without positional encoding)
+    whose time reduction is done by two transformer_temporal_enc_layer's on the conv2 output -- tokens = the T frames,
+    features = 72 bins x n_chan_layers[1] channels (so time_embed_dim must equal 72 * n_chan_layers[1]) -- followed by a crop
+    to the centre frames and a 1x1 `reduction` convolution (which takes n_chan_layers[2] channels: the class only runs with
+    n_chan_layers[1] == n_chan_layers[2], as upstream).  Six attention_time layers are constructed, two are used
+    (:1511-1516).  Output (B, 1, 1, T-74, 72) -- the reference's `.unsqueeze(1)` of a 4-D tensor."""
+
+    def __init__(self, n_chan_input=6, n_chan_layers=[64, 30, 20, 10], n_bins_in=216, n_bins_out=12, a_lrelu=0.3,
+                 p_dropout=0.2, scalefac=8, embed_dim=4 * 16, num_heads=8, mlp_dim=512,
+                 self_attn_depth=0, self_attn_number=2, time_embed_dim=256, pos_encoding=None):
+        _UNetTrunk.__init__(self)
+        self.attn_depth = self_attn_depth
+        self.attn_number = self_attn_number
+        context_frames = 75
+        self.half_context = context_frames // 2
+        self._build_trunk(n_chan_input, n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, scalefac)
+        self._attn_layers(embed_dim, num_heads, mlp_dim, p_dropout, None, self_attn_depth, self_attn_number)
+        self._build_decoder(n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, scalefac, head=False)
+        self.flatten = nn.Flatten(start_dim=-2, end_dim=-1)
+        for i in range(1, 7):
+            setattr(self, f"attention_time{i}", transformer_temporal_enc_layer(
+                embed_dim=time_embed_dim, num_heads=num_heads, mlp_dim=mlp_dim, p_dropout=p_dropout,
+                pos_encoding=pos_encoding if i == 1 else None))
+        self.reduction = nn.Sequential(
+            Conv2d(in_channels=n_chan_layers[2], out_channels=1, kernel_size=(1, 1), padding=(0, 0), stride=(1, 1)),
+            Sigmoid())
+
+    def forward(self, x):
+        x1, x2, x3, x4, x5 = self._encode(x)
+        x5 = self._attend(x5, 5, 0)
+        x4 = self._attend(x4, 4, 1)
+        x = self.upconv1(self.upconcat(x5, x4))
+        x3 = self._attend(x3, 3, 2)
+        x = self.upconv2(self.upconcat(x, x3))
+        x2 = self._attend(x2, 2, 3)
+        x = self.upconv3(self.upconcat(x, x2))
+        x1 = self._attend(x1, 1, 4)
+        x = self.upconv4(self.upconcat(x, x1))
+        x = self.conv2(x)                                           # (B, n1, T, 72)
+        B, n1, T, W = x.shape
+        l1, l2 = self.attention_time1, self.attention_time2
+        if W * n1 != l1.embed_dim:
+            raise RuntimeError(f"simple_u_net_doubleselfattn_transenc: time_embed_dim must be {W} * n_chan_layers[1] = {W * n1}, "
+                               f"got {l1.embed_dim}")
+        # x.transpose(1,3) -> (B, 72, T, n1) into the temporal layer, whose tokens are then [b, t, w * n1 + ch]: one transpose
+        # of the (B, n1, T*72) view instead of the reference's chain of four
+        seq = ops.transpose_last2(x.reshape(B, n1, T * W)).reshape(B, T, W * n1)
+        if l1.pos_encoding is not None:
+            if T > l1.pe.shape[0]:
+                raise RuntimeError(f"sequence of {T} frames exceeds the positional table ({l1.pe.shape[0]})")
+            seq = l1.dropout_pe(ops.add_rows(seq, l1._pe_on(seq.device)[:T]))
+        seq = l2._encode_tokens(l1._encode_tokens(seq))
+        x = ops.transpose_last2(seq.reshape(B, T * W, n1)).reshape(B, n1, T, W)      # = layer output .transpose(1, 3)
+        x = x[:, :, self.half_context:-self.half_context, :]
+        conv, _sig = self.reduction[0], self.reduction[1]
+        return conv(x.contiguous(), ops.ACT_SIGMOID, 0.0).unsqueeze(1)
+
+
+class _TemporalUNetTrunk(_UNetTrunk):
+    """Trunk of the two "temporal" U-Nets (unet_cnns.py:1117-1254, 1258-1365): pooling (2,3) -- 75x216 -> 37x72 -> 18x24 -> 9x8
+    -> 4x2 -- with channels 16 / 48 / 144 / 432 / 1728 over scalefac, so that channels x bins is the same 3456 / scalefac on
+    every level (the embed_dim of the time-axis layers); decoder with (2,3) bilinear upsampling."""
+
+    def _build_temporal(self, n_in, n_ch, n_bins_in, n_bins_out, a_lrelu, p_dropout, sc):
+        self.layernorm = LayerNorm(normalized_shape=[n_in, n_bins_in])
+        kp = lambda k: dict(kernel_size=(k, k), padding=(k // 2, k // 2))
+        self.inc = double_conv(in_channels=n_in, mid_channels=16 // sc, out_channels=16 // sc, **kp(15))
+        self.down1 = nn.Sequential(MaxPool2d((2, 3)), double_conv(in_channels=16 // sc, out_channels=48 // sc, mid_channels=48 // sc, **kp(15)))
+        self.down2 = nn.Sequential(MaxPool2d((2, 3)), double_conv(in_channels=48 // sc, out_channels=144 // sc, mid_channels=144 // sc, **kp(9)))
+        self.down3 = nn.Sequential(MaxPool2d((2, 3)), double_conv(in_channels=144 // sc, out_channels=432 // sc, mid_channels=432 // sc, **kp(5)))
+        self.down4 = nn.Sequential(MaxPool2d((2, 3)), double_conv(in_channels=432 // sc, out_channels=1728 // sc, mid_channels=1728 // sc, **kp(3)))
+
+    def _build_temporal_decoder(self, n_ch, n_bins_in, n_bins_out, a_lrelu, p_dropout, sc):
+        kp = lambda k: dict(kernel_size=(k, k), padding=(k // 2, k // 2))
+        self.upconcatsize2 = unet_up_concat_padding((2, 2))
+        self.upconcatsize3 = unet_up_concat_padding((2, 3))
+        self.upconv1 = double_conv(in_channels=(1728 + 432) // sc, out_channels=144 // sc, mid_channels=(1728 + 432) // (2 * sc), **kp(3))
+        self.upconv2 = double_conv(in_channels=2 * 144 // sc, out_channels=48 // sc, mid_channels=144 // sc, **kp(5))
+        self.upconv3 = double_conv(in_channels=2 * 48 // sc, out_channels=16 // sc, mid_channels=48 // sc, **kp(9))
+        self.upconv4 = double_conv(in_channels=2 * 16 // sc, out_channels=n_ch[0], mid_channels=48 // sc, **kp(15))
+        self.conv2, self.conv3, self.conv4 = _head(n_ch[0], n_ch, n_bins_in, n_bins_out, a_lrelu, p_dropout)
+
+    def _decode_temporal(self, x1, x2, x3, x4, x5, on_skip):
+        """on_skip(tensor, level): the level's time-axis layers (identity above the configured depth)"""
+        x5 = on_skip(x5, 5)
+        x4 = on_skip(x4, 4)
+        x = self.upconv1(self.upconcatsize3(x5, x4))
+        x3 = on_skip(x3, 3)
+        x = self.upconv2(self.upconcatsize3(x, x3))
+        x2 = on_skip(x2, 2)
+        x = self.upconv3(self.upconcatsize3(x, x2))
+        x1 = on_skip(x1, 1)
+        x = self.upconv4(self.upconcatsize3(x, x1))
+        return self.conv4(self.conv3(self.conv2(x)))
+
+
+class u_net_temporal_selfattn_varlayers(_TemporalUNetTrunk):
+    """unet_cnns.py:1117-1254: `self_attn_number` (0..2) transformer_temporal_enc_layer's on the bottleneck and on the skip
+    connections of the deepest `self_attn_depth` levels; embed_dim must be 3456 // scalefac (channels x bins of a level)."""
+
+    def __init__(self, n_chan_input=6, n_chan_layers=[64, 30, 20, 10], n_bins_in=216, n_bins_out=12, a_lrelu=0.3,
+                 p_dropout=0.2, scalefac=8, embed_dim=4 * 16, num_heads=8, mlp_dim=512, self_attn_depth=0,
+                 self_attn_number=2, pos_encoding=None):
+        super().__init__()
+        self.attn_depth = self_attn_depth
+        self.attn_number = self_attn_number
+        self._build_temporal(n_chan_input, n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, scalefac)
+        for lvl, level in enumerate((5, 4, 3, 2, 1)):
+            if self_attn_depth > lvl:
+                if self_attn_number > 0:
+                    setattr(self, f"attention{level}a", transformer_temporal_enc_layer(
+                        embed_dim=embed_dim, num_heads=num_heads, mlp_dim=mlp_dim, p_dropout=p_dropout, pos_encoding=pos_encoding))
+                if self_attn_number > 1:
+                    setattr(self, f"attention{level}b", transformer_temporal_enc_layer(
+                        embed_dim=embed_dim, num_heads=num_heads, mlp_dim=mlp_dim, p_dropout=p_dropout))
+        self._build_temporal_decoder(n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, scalefac)
+
+    def _on_skip(self, t, level):
+        if self.attn_depth > 5 - level:
+            if self.attn_number > 0:
+                t = getattr(self, f"attention{level}a")(t)
+            if self.attn_number > 1:
+                t = getattr(self, f"attention{level}b")(t)
+        return t
+
+    def forward(self, x):
+        return self._decode_temporal(*self._encode(x), self._on_skip)
+
+
+class u_net_temporal_blstm_varlayers(_TemporalUNetTrunk):
+    """unet_cnns.py:1258-1365: as u_net_temporal_selfattn_varlayers with a blstm_temporal_enc_layer (`lstm_number` stacked
+    bidirectional LSTM layers) per level instead of the transformer layers; needs 2 * hidden_size == embed_dim ==
+    3456 // scalefac."""
+
+    def __init__(self, n_chan_input=6, n_chan_layers=[64, 30, 20, 10], n_bins_in=216, n_bins_out=12, a_lrelu=0.3,
+                 p_dropout=0.2, scalefac=8, embed_dim=4 * 16, hidden_size=512, lstm_depth=0, lstm_number=2):
+        super().__init__()
+        self.lstm_depth = lstm_depth
+        self.lstm_number = lstm_number
+        self._build_temporal(n_chan_input, n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, scalefac)
+        self.flatten = nn.Flatten(start_dim=-3, end_dim=-2)
+        for lvl, level in enumerate((5, 4, 3, 2, 1)):
+            if lstm_depth > lvl:
+                setattr(self, f"lstm{level}", blstm_temporal_enc_layer(embed_dim=embed_dim, hidden_size=hidden_size,
+                                                                       num_layers=lstm_number, batch_first=True, bidirectional=True))
+        self._build_temporal_decoder(n_chan_layers, n_bins_in, n_bins_out, a_lrelu, p_dropout, scalefac)
+
+    def _on_skip(self, t, level):
+        return getattr(self, f"lstm{level}")(t) if self.lstm_depth > 5 - level else t
+
+    def forward(self, x):
+        return self._decode_temporal(*self._encode(x), self._on_skip)
 
 
 class simple_u_net_doubleselfattn_alllayers(simple_u_net_doubleselfattn_varlayers):

@@ -766,33 +766,36 @@ class UpCatFn(torch.autograd.Function):
     reads its gradient in place -- the first Cs channels of dout -- so no copy of that half is made."""
 
     @staticmethod
-    def forward(ctx, x1, x2, skip_view=False):
+    def forward(ctx, x1, x2, skip_view=False, factor=(2, 2)):
         ctx.skip_view = bool(skip_view)
         x1, x2 = _c(x1), _c(x2)
         B, C1, H1, W1 = x1.shape
         B2, Cs, Hs, Ws = x2.shape
-        if B != B2 or Hs < 2 * H1 or Ws < 2 * W1:
-            raise RuntimeError(f"upconcat: skip {tuple(x2.shape)} smaller than upsampled {tuple(x1.shape)}")
+        fh, fw = int(factor[0]), int(factor[1])
+        if B != B2 or Hs < fh * H1 or Ws < fw * W1:
+            raise RuntimeError(f"upconcat: skip {tuple(x2.shape)} smaller than upsampled {tuple(x1.shape)} x {factor}")
         out = torch.empty((B, Cs + C1, Hs, Ws), dtype=torch.float32, device=x1.device)
-        _chk(_lib().mpa_upcat_fwd(_p(x1), _p(x2), _p(out), B, C1, H1, W1, Cs, Hs, Ws, _s()), "mpa_upcat_fwd")
-        ctx.geom = (B, C1, H1, W1, Cs, Hs, Ws)
+        _chk(_lib().mpa_upcat_scaled_fwd(_p(x1), _p(x2), _p(out), B, C1, H1, W1, Cs, Hs, Ws, fh, fw, _s()), "mpa_upcat_scaled_fwd")
+        ctx.geom = (B, C1, H1, W1, Cs, Hs, Ws, fh, fw)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        B, C1, H1, W1, Cs, Hs, Ws = ctx.geom
+        B, C1, H1, W1, Cs, Hs, Ws, fh, fw = ctx.geom
         dout = _c(dout)
         dx1 = torch.empty((B, C1, H1, W1), dtype=torch.float32, device=dout.device)
         if ctx.skip_view:
-            _chk(_lib().mpa_upcat_bwd(_p(dout), _p(dx1), None, B, C1, H1, W1, Cs, Hs, Ws, _s()), "mpa_upcat_bwd")
-            return dx1, dout[:, :Cs], None
+            _chk(_lib().mpa_upcat_scaled_bwd(_p(dout), _p(dx1), None, B, C1, H1, W1, Cs, Hs, Ws, fh, fw, _s()),
+                 "mpa_upcat_scaled_bwd")
+            return dx1, dout[:, :Cs], None, None
         dskip = torch.empty((B, Cs, Hs, Ws), dtype=torch.float32, device=dout.device)
-        _chk(_lib().mpa_upcat_bwd(_p(dout), _p(dx1), _p(dskip), B, C1, H1, W1, Cs, Hs, Ws, _s()), "mpa_upcat_bwd")
-        return dx1, dskip, None
+        _chk(_lib().mpa_upcat_scaled_bwd(_p(dout), _p(dx1), _p(dskip), B, C1, H1, W1, Cs, Hs, Ws, fh, fw, _s()),
+             "mpa_upcat_scaled_bwd")
+        return dx1, dskip, None, None
 
 
-def upconcat(x1, x2):
-    return UpCatFn.apply(x1, x2, bool(getattr(x2, "_mpa_pool_skip", False)))
+def upconcat(x1, x2, factor=(2, 2)):
+    return UpCatFn.apply(x1, x2, bool(getattr(x2, "_mpa_pool_skip", False)), tuple(factor))
 
 
 # --------------------------------------------------------------------------- pointwise
@@ -923,6 +926,33 @@ class AddFn(torch.autograd.Function):
 
 def add(a, b):
     return AddFn.apply(a, b)
+
+
+class AddRowsFn(torch.autograd.Function):
+    """x (B, ...) + pe (...): a positional table added to every sample (transformer_temporal_enc_layer, unet_cnns.py:211)."""
+
+    @staticmethod
+    def forward(ctx, x, pe):
+        x, pe = _c(x, "input"), _c(pe, "positional table")
+        if tuple(x.shape[1:]) != tuple(pe.shape):
+            raise RuntimeError(f"add_rows: table {tuple(pe.shape)} does not match the samples {tuple(x.shape[1:])}")
+        y = torch.empty_like(x)
+        _chk(_lib().mpa_add_rows_bcast(_p(x), _p(pe), _p(y), x.shape[0], pe.numel(), _s()), "mpa_add_rows_bcast")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        dpe = None
+        if ctx.needs_input_grad[1]:
+            B, n = dy.shape[0], dy.numel() // dy.shape[0]
+            dpe = torch.empty(dy.shape[1:], dtype=torch.float32, device=dy.device)
+            _chk(_lib().mpa_colsum(_p(dy), _p(dpe), B, n, 0, _s()), "mpa_colsum")
+        return dy, dpe
+
+
+def add_rows(x, pe):
+    return AddRowsFn.apply(x, pe)
 
 
 class LogSoftmaxCatFn(torch.autograd.Function):

@@ -51,14 +51,46 @@ def variant_loss(name, res, y):
     if "logsoftmax" in name:
         return (res * logsoftmax_weights(tuple(res.shape), res.dtype)).mean()
     two = isinstance(res, tuple)
+    if not two and res.dim() == 5:           # simple_u_net_doubleselfattn_transenc returns (B,1,1,T-74,72)
+        res = res.squeeze(1)
     loss = torch.nn.BCELoss()(res[0] if two else res, y)
     if two:      # a loss that reaches the polyphony head whatever its width: mean of its (ReLU) output
         loss = loss + res[1].mean() / 25.0
     return loss
 
 
+# the exported *layer* transformer_temporal_enc_layer on its own (B, C, T', F') interface
+LAYER_CASES = {"transformer_temporal_enc_layer": (dict(embed_dim=24, num_heads=4, mlp_dim=16, p_dropout=0.0,
+                                                       pos_encoding="sinusoidal"), (3, 4, 10, 6))}
+
+
+def layer_goldens():
+    for name, (kwargs, shape) in LAYER_CASES.items():
+        with unittest.mock.patch("torch.zeros", _zeros_cpu):
+            layer = getattr(ref_models, name)(**kwargs).double()
+        layer.load_state_dict(det_fill(layer.state_dict()))
+        layer.pe = layer.pe.double()
+        x = torch.randn(shape, generator=torch.Generator().manual_seed(7), dtype=torch.float64, requires_grad=True)
+        layer.train()                      # (p_dropout = 0)
+        y = layer(x)
+        w = logsoftmax_weights(tuple(y.shape), y.dtype)
+        (y * w).sum().backward()
+        out = {"schema": np.array(json.dumps({k: list(v.shape) for k, v in layer.state_dict().items()})),
+               "kwargs": np.array(json.dumps(kwargs)), "x": x.detach().numpy(), "y": y.detach().numpy(),
+               "dx": x.grad.numpy()}
+        for k, p in layer.named_parameters():
+            out[f"grad.{k}"] = p.grad.numpy()
+        np.savez_compressed(os.path.join(GOLDEN_DIR, f"xlayer-{name}.npz"), **out)
+        print(f"{name:48s} y[min,max]=({out['y'].min():.4f},{out['y'].max():.4f})", flush=True)
+
+
 def main():
+    only = set(sys.argv[1:])
+    if not only or only & set(LAYER_CASES):
+        layer_goldens()
     for name, kwargs in VARIANT_CONFIGS.items():
+        if only and name not in only:
+            continue
         B, T = 3, 75
         with unittest.mock.patch("torch.zeros", _zeros_cpu):
             model = getattr(ref_models, name)(**kwargs)
@@ -86,6 +118,8 @@ def main():
         out["train.loss"] = np.array(loss.item())
         out["train.y"] = (res[0] if two else res).detach().numpy()
         for k, p in model.named_parameters():
+            if p.grad is None:           # constructed but unused (attention_time3..6 of the _transenc class)
+                continue
             out[f"grad.{k}.norm"] = np.array(p.grad.double().norm().item())
             out[f"grad.{k}.absmax"] = np.array(p.grad.abs().max().item())
             out[f"grad.{k}.samples"] = p.grad.numpy().ravel()[sample_idx(p.grad.numel())]
@@ -105,6 +139,8 @@ def main():
         l64.backward()
         out["train.loss64"] = np.array(l64.item())
         for k, p in m64.named_parameters():
+            if p.grad is None:
+                continue
             out[f"grad64.{k}.samples"] = p.grad.numpy().ravel()[sample_idx(p.grad.numel())]
             out[f"grad64.{k}.absmax"] = np.array(p.grad.abs().max().item())
         np.savez_compressed(os.path.join(GOLDEN_DIR, f"xcls-{name}.npz"), **out)

@@ -877,3 +877,26 @@ def test_fanout_adds_the_two_gradients(dev):
     with torch.no_grad():
         a, b = ops.fanout(x)
         assert a is x and b is x
+
+
+@pytest.mark.parametrize("g", [(2, 5, 4, 2, 3, 9, 8, (2, 3)), (1, 3, 9, 8, 2, 18, 24, (2, 3)), (2, 2, 18, 24, 1, 37, 72, (2, 3)),
+                               (1, 2, 5, 7, 2, 17, 23, (3, 3)), (1, 1, 6, 6, 1, 6, 13, (1, 2))],
+                         ids=lambda g: "x".join(map(str, g[:7])) + f"-f{g[7][0]}{g[7][1]}")
+def test_upconcat_other_factors(dev, g):
+    """unet_up_concat_padding((2,3)) of the temporal U-Nets (unet_cnns.py:1185) and other factors up to 4: bilinear
+    align_corners upsampling by (fh, fw), zero padding to the skip tensor's size, concatenation -- against torch"""
+    from multipitch_architectures_amd import ops
+    B, C1, H1, W1, Cs, Hs, Ws, f = g
+    x1, x2 = _rand((B, C1, H1, W1), 1), _rand((B, Cs, Hs, Ws), 2)
+    a, b = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    up = F.interpolate(a, scale_factor=f, mode="bilinear", align_corners=True)
+    dY, dX = Hs - up.shape[2], Ws - up.shape[3]
+    ref = torch.cat([b, F.pad(up, [dX // 2, dX - dX // 2, dY // 2, dY - dY // 2])], dim=1)
+    gy = _rand(tuple(ref.shape), 3)
+    ref.backward(gy)
+    ag, bg = x1.to(dev).requires_grad_(True), x2.to(dev).requires_grad_(True)
+    out = ops.upconcat(ag, bg, f)
+    out.backward(gy.to(dev))
+    _close(out, ref, 2e-6)
+    _close(ag.grad, a.grad, 1e-5)
+    _close(bg.grad, b.grad, 1e-7)

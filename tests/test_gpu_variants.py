@@ -60,6 +60,8 @@ def test_variant_matches_the_reference(dev, name):
             m.p = 0.0
     model.train()
     res = model(x)
+    if not two and res.dim() == 5:       # simple_u_net_doubleselfattn_transenc: (B,1,1,T-74,72)
+        res = res.squeeze(1)
     if lsm:      # the linear loss of oracle/make_goldens_variants.py: variant_loss (test-side torch arithmetic on the HIP output)
         n = res.numel()
         wpat = torch.cos(torch.arange(n, dtype=torch.float64) * 0.37).reshape(res.shape).float().to(dev)
@@ -75,9 +77,37 @@ def test_variant_matches_the_reference(dev, name):
     for k, p in model.named_parameters():
         if k.endswith(("double_conv.0.bias", "double_conv.4.bias")):
             continue        # conv bias in front of a BatchNorm: the true gradient is exactly 0, both sides hold rounding noise
+        if f"grad.{k}.samples" not in g.files:
+            assert p.grad is None, k          # constructed but unused upstream as well (attention_time3..6)
+            continue
         r32 = g[f"grad.{k}.samples"].astype(np.float64)
         r64 = g[f"grad64.{k}.samples"]
         mine = p.grad.detach().cpu().numpy().ravel()[_sample_idx(p.numel())].astype(np.float64)
         scale = float(g[f"grad64.{k}.absmax"])
         tol = 20.0 * np.abs(r32 - r64).max() + 2e-2 * scale + 1e-9
         assert np.abs(mine - r64).max() <= tol, (k, np.abs(mine - r64).max(), tol)
+
+
+def test_transformer_temporal_enc_layer_matches_the_reference(dev):
+    """the exported layer on its own (B, C, T', F') interface (unet_cnns.py:162-217) against the reference layer run in
+    float64 (oracle/make_goldens_variants.py: layer_goldens): output, input gradient and every parameter gradient"""
+    g = np.load(os.path.join(GOLDEN_DIR, "xlayer-transformer_temporal_enc_layer.npz"))
+    kwargs = json.loads(str(g["kwargs"]))
+    layer = nn_models.transformer_temporal_enc_layer(**kwargs)
+    assert {k: list(v.shape) for k, v in layer.state_dict().items()} == json.loads(str(g["schema"]))
+    layer.load_state_dict(det_fill(layer.state_dict()))
+    layer.to(dev).train()
+    x = torch.from_numpy(g["x"]).float().to(dev).requires_grad_(True)
+    y = layer(x)
+    n = y.numel()
+    w = torch.cos(torch.arange(n, dtype=torch.float64) * 0.37).reshape(y.shape).float().to(dev)
+    (y * w).sum().backward()
+
+    def close(a, ref, what):
+        a, ref = a.detach().cpu().double().numpy(), np.asarray(ref, dtype=np.float64)
+        assert a.shape == ref.shape, what
+        assert np.abs(a - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-6), (what, np.abs(a - ref).max(), np.abs(ref).max())
+    close(y, g["y"], "y")
+    close(x.grad, g["dx"], "dx")
+    for k, p in layer.named_parameters():
+        close(p.grad, g[f"grad.{k}"], k)
