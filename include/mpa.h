@@ -33,6 +33,8 @@ extern "C" {
 #define MPA_ACT_RELU 1
 #define MPA_ACT_LRELU 2
 #define MPA_ACT_SIGMOID 3
+#define MPA_ACT_SELU 5      /* nn.SELU: 1.0507 * (x > 0 ? x : 1.6733 * (exp(x) - 1)) -- the frequency U-Nets (unet_cnns.py:1711-1765); only
+                               mpa_act_fwd / mpa_act_bwd take it (not a fused convolution epilogue) */
 #define MPA_ACT_ELU 4       /* nn.ELU(alpha=1): x > 0 ? x : exp(x) - 1  (double_conv alt_order, unet_cnns.py:60-70) */
 
 const char* mpa_strerror(int code);
@@ -189,6 +191,11 @@ int mpa_maxpool2d_bwd(const float* dy, const int32_t* idx, float* dx, int B, int
  * the concatenated gradient, read in place).  One pass instead of the pool backward, a slice copy and an add.            */
 int mpa_maxpool2d_bwd_add(const float* dy, const int32_t* idx, const float* add /*nullable*/, int64_t add_batch_stride,
                           float* dx, int B, int C, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, void* stream);
+/* nn.MaxUnpool2d(kernel) with the indices of a non-overlapping MaxPool2d(kernel, return_indices=True) (stride == kernel, no
+ * padding; unet_cnns.py:1751-1765): y (B,C,OH*kh,OW*kw), y[idx[o]] = x[o], zeros elsewhere -- in gather form (every output
+ * position belongs to exactly one window), so no zero fill and no scatter.  Backward: dx[o] = dy[idx[o]].               */
+int mpa_maxunpool2d_fwd(const float* x, const int32_t* idx, float* y, int B, int C, int OH, int OW, int kh, int kw, void* stream);
+int mpa_maxunpool2d_bwd(const float* dy, const int32_t* idx, float* dx, int B, int C, int OH, int OW, int kh, int kw, void* stream);
 /* unet_up_concat_padding (unet_cnns.py:93-104): out = cat([skip, pad(bilinear_x2_align_corners(x1))], dim=1) */
 int mpa_upcat_fwd(const float* x1, const float* skip, float* out, int B, int C1, int H1, int W1, int Cs, int Hs,
                   int Ws, void* stream);

@@ -88,6 +88,8 @@ SIGNATURES = {
     "mpa_attn_batchaxis_bwd_kv": (c_int, [_P] * 9 + [c_int, c_int, c_int, c_int, c_int, _P]),
     "mpa_maxpool2d_fwd": (c_int, [_P, _P, _P] + [c_int] * 10 + [_P]),
     "mpa_maxpool2d_bwd": (c_int, [_P, _P, _P] + [c_int] * 10 + [_P]),
+    "mpa_maxunpool2d_fwd": (c_int, [_P, _P, _P] + [c_int] * 6 + [_P]),
+    "mpa_maxunpool2d_bwd": (c_int, [_P, _P, _P] + [c_int] * 6 + [_P]),
     "mpa_maxpool2d_bwd_add": (c_int, [_P, _P, _P, c_int64, _P] + [c_int] * 10 + [_P]),
     "mpa_upcat_fwd": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P]),
     "mpa_upcat_bwd": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P]),

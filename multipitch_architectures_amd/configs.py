@@ -112,6 +112,9 @@ VARIANT_CONFIGS = {
                                               pos_encoding="sinusoidal"),
     "u_net_temporal_blstm_varlayers": dict(n_chan_layers=[8, 6, 5, 4], n_bins_out=72, scalefac=16, embed_dim=216,
                                            hidden_size=108, lstm_depth=2, lstm_number=1),
+    "freq_u_net_selfattn": dict(n_chan_layers=[8, 6, 5, 4], n_bins_out=72, scalefac=4, embed_dim=24, num_heads=4, mlp_dim=20),
+    "freq_u_net_doubleselfattn": dict(n_chan_layers=[8, 6, 5, 4], n_bins_out=72, scalefac=4, embed_dim=24, num_heads=4,
+                                      mlp_dim=20),
     "basic_cnn": dict(n_chan_layers=[8, 6, 5, 4], n_bins_out=72),
     "basic_cnn_pool": dict(n_chan_layers=[8, 6, 5, 4], n_bins_out=72),
     "basic_cnn_segm_logsoftmax": dict(n_chan_layers=[8, 6, 5, 4], n_ch_out=3, n_bins_out=72),

@@ -33,6 +33,7 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ 
     const float v = x[i];
     float r;
     if (act == MPA_ACT_SIGMOID) r = 1.f / (1.f + expf(-v));
+    else if (act == MPA_ACT_SELU) r = 1.0507009873554805f * (v > 0.f ? v : 1.6732632423543772f * expm1f(v));
     else r = mpa_apply_act(v, act, slope);
     y[i] = r;
   }
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
       case MPA_ACT_LRELU: r = v >= 0.f ? g : g * slope; break;
       case MPA_ACT_SIGMOID: r = g * v * (1.f - v); break;
       case MPA_ACT_ELU: r = v > 0.f ? g : g * (v + 1.f); break;      // v = y: y <= 0 <=> x <= 0, dy/dx = exp(x) = y + 1
+      case MPA_ACT_SELU: r = v > 0.f ? g * 1.0507009873554805f : g * (v + 1.0507009873554805f * 1.6732632423543772f); break;   // v = y
       default: r = g;
     }
     dx[i] = r;

@@ -71,6 +71,28 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
   }
 }
 
+// MaxUnpool2d of a non-overlapping pooling in gather form: output element i = (plane, h, w) belongs to window
+// (h / kh, w / kw) and takes that window's value iff the window's argmax is (h, w)
+__global__ __launch_bounds__(256) void maxunpool_fwd_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx,
+                                                            float* __restrict__ y, long n, int OH, int OW, int kh, int kw) {
+  const int H = OH * kh, W = OW * kw;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long pl = i / ((long)H * W);
+    const int r = (int)(i - pl * H * W);
+    const int h = r / W, w = r - h * W;
+    const long o = pl * OH * OW + (long)(h / kh) * OW + (w / kw);
+    y[i] = idx[o] == r ? x[o] : 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void maxunpool_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ idx,
+                                                            float* __restrict__ dx, long n, int n_pooled, int n_plane) {
+  for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < n; o += (long)gridDim.x * 256) {
+    const long pl = o / n_pooled;
+    const int t = idx[o];
+    dx[o] = (t >= 0 && t < n_plane) ? dy[pl * n_plane + t] : 0.f;
+  }
+}
+
 // Plane-in-LDS variants: one workgroup owns one (b, c) plane, stages it in LDS with contiguous loads and forms every
 // window from LDS -- each input element crosses HBM once even for tall windows (the head's 13x1 stride-1 pool re-reads
 // every row 13 times otherwise).
@@ -667,6 +689,20 @@ int mpa_maxpool2d_bwd_add(const float* dy, const int32_t* idx, const float* add,
   }
   MPA_LAUNCH(maxpool_bwd_kernel, dim3(row_blocks(planes * H)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx,
                      planes * H, H, W, OH, OW, kh, kw, sh, sw, ph, pw, add, C, (long)add_batch_stride);
+  return mpa_launch_status();
+}
+
+int mpa_maxunpool2d_fwd(const float* x, const int32_t* idx, float* y, int B, int C, int OH, int OW, int kh, int kw, void* stream) {
+  if (!x || !idx || !y || kh < 1 || kw < 1 || OH < 1 || OW < 1) return MPA_ERR_ARG;
+  const long n = (long)B * C * OH * kh * OW * kw;
+  MPA_LAUNCH(maxunpool_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, idx, y, n, OH, OW, kh, kw);
+  return mpa_launch_status();
+}
+int mpa_maxunpool2d_bwd(const float* dy, const int32_t* idx, float* dx, int B, int C, int OH, int OW, int kh, int kw, void* stream) {
+  if (!dy || !idx || !dx || kh < 1 || kw < 1 || OH < 1 || OW < 1) return MPA_ERR_ARG;
+  const long n = (long)B * C * OH * OW;
+  MPA_LAUNCH(maxunpool_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, n, OH * OW,
+             OH * kh * OW * kw);
   return mpa_launch_status();
 }
 

@@ -153,14 +153,32 @@ class LSTM(nn.Module):
 
 
 class MaxPool2d(nn.Module):
-    def __init__(self, kernel_size, stride=None, padding=(0, 0)):
+    def __init__(self, kernel_size, stride=None, padding=(0, 0), return_indices=False):
         super().__init__()
         self.kernel_size = _pair(kernel_size)
         self.stride = self.kernel_size if stride is None else _pair(stride)
         self.padding = _pair(padding)
+        self.return_indices = bool(return_indices)
+        if self.return_indices and (self.stride != self.kernel_size or self.padding != (0, 0)):
+            raise NotImplementedError("return_indices is built for non-overlapping windows (stride == kernel, no padding)")
 
     def forward(self, x):
+        if self.return_indices:
+            return ops.max_pool2d_with_indices(x, self.kernel_size)
         return ops.max_pool2d(x, self.kernel_size, self.stride, self.padding)
+
+
+class MaxUnpool2d(nn.Module):
+    """nn.MaxUnpool2d(kernel_size) (stride == kernel): unet_cnns.py:1751-1765"""
+
+    def __init__(self, kernel_size, stride=None, padding=(0, 0)):
+        super().__init__()
+        self.kernel_size = _pair(kernel_size)
+        if (stride is not None and _pair(stride) != self.kernel_size) or _pair(padding) != (0, 0):
+            raise NotImplementedError("MaxUnpool2d is built for stride == kernel_size, no padding")
+
+    def forward(self, x, indices):
+        return ops.max_unpool2d(x, indices, self.kernel_size)
 
 
 class _Pointwise(nn.Module):
@@ -200,6 +218,14 @@ class LogSoftmax(nn.Module):
 
     def forward(self, x, other=None):
         return ops.logsoftmax_cat(x, other)
+
+
+class SELU(_Pointwise):
+    """nn.SELU -- the frequency U-Nets (unet_cnns.py:1711-1765)"""
+    act = ops.ACT_SELU
+
+    def __init__(self, inplace=False):
+        super().__init__()
 
 
 class ELU(_Pointwise):

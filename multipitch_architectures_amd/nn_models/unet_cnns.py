@@ -10,7 +10,7 @@ import torch.nn as nn
 from .. import ops
 from .basic_cnns import _head
 from .layers import (BatchNorm2d, Conv2d, ConvActPoolDrop, Dropout, ELU, LayerNorm, LeakyReLU, Linear, LSTM, MaxPool2d,
-                     MultiheadAttention, ReLU, Sigmoid)
+                     MaxUnpool2d, MultiheadAttention, ReLU, SELU, Sigmoid)
 
 
 class _DoubleConvSeq(nn.Sequential):
@@ -669,6 +669,102 @@ class u_net_temporal_blstm_varlayers(_TemporalUNetTrunk):
 
     def forward(self, x):
         return self._decode_temporal(*self._encode(x), self._on_skip)
+
+
+class _FreqStage(nn.Sequential):
+    """[BatchNorm2d ->] Conv2d -> SELU of the frequency U-Nets (unet_cnns.py:1710-1765)"""
+
+    def forward(self, x):
+        h = x
+        for m in self:
+            h = m(h, relu=False) if isinstance(m, BatchNorm2d) else m(h)
+        return h
+
+
+class freq_u_net_selfattn(nn.Module):
+    """unet_cnns.py:1691-1814: a U-Net that pools along frequency only -- on (B, C, bins, frames) tensors: 216 -> 72 -> 9 -> 1
+    bins by MaxPool2d((3,1)) / ((8,1)) / ((9,1)) with return_indices -- SELU activations, MaxUnpool2d with the transferred
+    pooling indices as skip strategy, and at the one-bin bottleneck a transformer block on the (B, frames, channels) tokens
+    (nn.MultiheadAttention with batch_first=False again: attention over the batch axis, Appendix C.1)."""
+
+    N_BLOCKS = 1
+
+    def __init__(self, n_chan_input=6, n_chan_layers=[32, 30, 20, 10], n_bins_in=216, n_bins_out=72, a_lrelu=0.3,
+                 p_dropout=0.2, scalefac=1, embed_dim=64, num_heads=8, mlp_dim=512):
+        super().__init__()
+        n_ch, sc = n_chan_layers, scalefac
+        assert embed_dim % num_heads == 0, 'embed_dim must be a multiple of num_heads!'
+        self.num_heads, self.embed_dim, self.head_dim = num_heads, embed_dim, embed_dim // num_heads
+        c1, c2, c3 = int(32 / sc), int(64 / sc), int(128 / sc)
+        self.layernorm = LayerNorm(normalized_shape=[n_chan_input, n_bins_in])
+        self.conv1 = _FreqStage(Conv2d(6, c1, 5, padding=2), SELU())
+        self.pool1 = MaxPool2d((3, 1), return_indices=True)
+        self.conv2 = _FreqStage(BatchNorm2d(c1), Conv2d(c1, c2, 5, padding=2), SELU())
+        self.pool2 = MaxPool2d((8, 1), return_indices=True)
+        self.conv3 = _FreqStage(BatchNorm2d(c2), Conv2d(c2, c3, 3, padding=1), SELU())
+        self.pool3 = MaxPool2d((9, 1), return_indices=True)
+        # transformer block(s) at the bottleneck: attribute names of the reference (no suffix, then "2")
+        for blk in range(self.N_BLOCKS):
+            sfx = "" if blk == 0 else str(blk + 1)
+            n_attn, n_mlp = 5 + 2 * blk, 6 + 2 * blk
+            setattr(self, "q_linear" + sfx, Linear(c3, embed_dim, bias=False))
+            setattr(self, "v_linear" + sfx, Linear(c3, embed_dim, bias=False))
+            setattr(self, "k_linear" + sfx, Linear(c3, embed_dim, bias=False))
+            setattr(self, "attn" + sfx, MultiheadAttention(embed_dim=embed_dim, num_heads=num_heads))
+            setattr(self, "o_linear" + sfx, Linear(embed_dim, c3, bias=False))
+            setattr(self, f"dropout{n_attn}", Dropout(p=p_dropout))
+            setattr(self, f"layernorm{n_attn}", LayerNorm(normalized_shape=[c3]))
+            setattr(self, f"mlp{n_mlp}", nn.Sequential(Linear(c3, mlp_dim), ReLU(), Linear(mlp_dim, c3)))
+            setattr(self, f"dropout{n_mlp}", Dropout(p=p_dropout))
+            setattr(self, f"layernorm{n_mlp}", LayerNorm(normalized_shape=[c3]))
+        self.up_pool3 = MaxUnpool2d((9, 1))
+        self.up_conv3 = _FreqStage(BatchNorm2d(c3), Conv2d(c3, c2, 3, padding=1), SELU())
+        self.up_pool2 = MaxUnpool2d((8, 1))
+        self.up_conv2 = _FreqStage(BatchNorm2d(c2), Conv2d(c2, c1, 5, padding=2), SELU())
+        self.up_pool1 = MaxUnpool2d((3, 1))
+        self.up_conv1 = _FreqStage(BatchNorm2d(c1), Conv2d(c1, int(n_ch[0] / sc), 5, padding=2), SELU())
+        # binning to MIDI pitches, time reduction, chroma reduction: the usual head under the names conv4 / conv5 / conv6
+        self.conv4, self.conv5, self.conv6 = _head(int(n_ch[0] / sc), n_ch, n_bins_in, n_bins_out, a_lrelu, p_dropout)
+
+    @staticmethod
+    def _swap(x):
+        """(B, C, H, W) -> (B, C, W, H)"""
+        B, C, H, W = x.shape
+        return ops.transpose_last2(x.reshape(B * C, H, W)).reshape(B, C, W, H)
+
+    def _block(self, t, blk):
+        sfx = "" if blk == 0 else str(blk + 1)
+        n_attn, n_mlp = 5 + 2 * blk, 6 + 2 * blk
+        g = lambda name: getattr(self, name)
+        t, t_res = ops.fanout(t)
+        q, k, v = ops.qkv_linear(t, g("q_linear" + sfx).weight, g("k_linear" + sfx).weight, g("v_linear" + sfx).weight)
+        a = g("o_linear" + sfx)(g("attn" + sfx)(q, k, v)[0])
+        a_norm, a_res = ops.fanout(g(f"layernorm{n_attn}")(t_res, g(f"dropout{n_attn}")(a)))
+        mlp = g(f"mlp{n_mlp}")
+        m = mlp[2](mlp[0](a_norm, ops.ACT_RELU))
+        return g(f"layernorm{n_mlp}")(a_res, g(f"dropout{n_mlp}")(m))
+
+    def forward(self, x):
+        x_norm = self._swap(self.layernorm.forward_cf(x))              # (B, 6, bins, frames)
+        c1, ind1 = self.pool1(self.conv1(x_norm))
+        c2, ind2 = self.pool2(self.conv2(c1))
+        c3, ind3 = self.pool3(self.conv3(c2))
+        B, C, one, T = c3.shape
+        if one != 1:
+            raise RuntimeError(f"freq_u_net: the three poolings must reduce the {x.shape[3]} bins to 1, got {one}")
+        t = ops.transpose_last2(c3.reshape(B, C, T))                    # (B, frames, channels)
+        for blk in range(self.N_BLOCKS):
+            t = self._block(t, blk)
+        bott = ops.transpose_last2(t).reshape(B, C, 1, T)
+        u3 = self.up_conv3(self.up_pool3(bott, ind3))
+        u2 = self.up_conv2(self.up_pool2(u3, ind2))
+        u1 = self.up_conv1(self.up_pool1(u2, ind1))
+        return self.conv6(self.conv5(self.conv4(self._swap(u1))))
+
+
+class freq_u_net_doubleselfattn(freq_u_net_selfattn):
+    """unet_cnns.py:1820-1961: freq_u_net_selfattn with two transformer blocks at the bottleneck (q_linear2 .. layernorm8)."""
+    N_BLOCKS = 2
 
 
 class simple_u_net_doubleselfattn_alllayers(simple_u_net_doubleselfattn_varlayers):

@@ -13,7 +13,7 @@ import torch
 from . import _lib as L
 from ._lib import ConvDesc
 
-ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_ELU = 0, 1, 2, 3, 4
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_ELU, ACT_SELU = 0, 1, 2, 3, 4, 5   # (SELU: activation() only, never fused)
 BN_EPS = 1e-5
 LN_EPS = 1e-5
 
@@ -678,6 +678,72 @@ class MaxPool2dFn(torch.autograd.Function):
 def max_pool2d(x, kernel, stride=None, padding=(0, 0)):
     stride = kernel if stride is None else stride
     return MaxPool2dFn.apply(x, tuple(kernel), tuple(stride), tuple(padding))
+
+
+class MaxPoolIdxFn(torch.autograd.Function):
+    """nn.MaxPool2d(kernel, return_indices=True) with stride == kernel (unet_cnns.py:1715-1729): (y, indices); the indices
+    (flat offsets inside each H*W plane, int32 here, int64 upstream) feed MaxUnpoolFn and are not differentiable."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        x = _c(x)
+        B, C, H, W = x.shape
+        OH, OW = H // k[0], W // k[1]
+        if OH <= 0 or OW <= 0:
+            raise RuntimeError(f"max_pool2d: window {k} larger than input {(H, W)}")
+        y = torch.empty((B, C, OH, OW), dtype=torch.float32, device=x.device)
+        idx = torch.empty((B, C, OH, OW), dtype=torch.int32, device=x.device)
+        _chk(_lib().mpa_maxpool2d_fwd(_p(x), _p(y), ctypes.c_void_p(idx.data_ptr()), B, C, H, W, k[0], k[1], k[0], k[1], 0, 0,
+                                     _s()), "mpa_maxpool2d_fwd")
+        ctx.geom = (B, C, H, W, k)
+        ctx.save_for_backward(idx)
+        ctx.mark_non_differentiable(idx)
+        return y, idx
+
+    @staticmethod
+    def backward(ctx, dy, _didx):
+        (idx,) = ctx.saved_tensors
+        B, C, H, W, k = ctx.geom
+        dy = _c(dy)
+        dx = torch.empty((B, C, H, W), dtype=torch.float32, device=dy.device)
+        _chk(_lib().mpa_maxpool2d_bwd(_p(dy), ctypes.c_void_p(idx.data_ptr()), _p(dx), B, C, H, W, k[0], k[1], k[0], k[1], 0, 0,
+                                     _s()), "mpa_maxpool2d_bwd")
+        return dx, None
+
+
+def max_pool2d_with_indices(x, kernel):
+    return MaxPoolIdxFn.apply(x, tuple(kernel))
+
+
+class MaxUnpoolFn(torch.autograd.Function):
+    """nn.MaxUnpool2d(kernel)(x, indices) for the indices of max_pool2d_with_indices (stride == kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, idx, k):
+        x = _c(x)
+        B, C, OH, OW = x.shape
+        if idx.dtype != torch.int32 or tuple(idx.shape) != (B, C, OH, OW) or not idx.is_contiguous():
+            raise RuntimeError("max_unpool2d: indices must be the contiguous int32 tensor max_pool2d_with_indices returned")
+        y = torch.empty((B, C, OH * k[0], OW * k[1]), dtype=torch.float32, device=x.device)
+        _chk(_lib().mpa_maxunpool2d_fwd(_p(x), ctypes.c_void_p(idx.data_ptr()), _p(y), B, C, OH, OW, k[0], k[1], _s()),
+             "mpa_maxunpool2d_fwd")
+        ctx.k = k
+        ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        B, C, OH, OW = idx.shape
+        dy = _c(dy)
+        dx = torch.empty((B, C, OH, OW), dtype=torch.float32, device=dy.device)
+        _chk(_lib().mpa_maxunpool2d_bwd(_p(dy), ctypes.c_void_p(idx.data_ptr()), _p(dx), B, C, OH, OW, ctx.k[0], ctx.k[1], _s()),
+             "mpa_maxunpool2d_bwd")
+        return dx, None, None
+
+
+def max_unpool2d(x, indices, kernel):
+    return MaxUnpoolFn.apply(x, indices, tuple(kernel))
 
 
 class PoolSkipFn(torch.autograd.Function):

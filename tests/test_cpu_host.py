@@ -56,9 +56,14 @@ def test_import_surface_matches_reference():
     assert len(names) == 32
     for n in names:
         assert hasattr(nn_models, n), n
-    with pytest.raises(NotImplementedError):
-        nn_models.freq_u_net_selfattn()
-    assert len(nn_models.BUILT) + len(nn_models.NOT_BUILT) == 32 and len(nn_models.NOT_BUILT) == 5
+    # the three names the reference itself cannot construct fail with the reference's exception classes (Appendix C.7)
+    with pytest.raises(NameError):
+        nn_models.freq_u_net()
+    with pytest.raises(NameError):
+        nn_models.freq_u_net_bottomstack()
+    with pytest.raises(UnboundLocalError):
+        nn_models.single_conv(4, 4)
+    assert len(nn_models.BUILT) + len(nn_models.NOT_BUILT) == 32 and len(nn_models.NOT_BUILT) == 3
 
 
 def test_constructor_signatures_verbatim():
