@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(const float* __restrict
 
 // the MFMA kernels take head dimension 16 with 16-byte-aligned head slices
 inline bool attn16_ok(int E, int heads, const void* a, const void* b, const void* c, const void* d2) {
-  return E / heads == 16 && E % 4 == 0 &&
+  return !mpa_diag().attn_valu && E / heads == 16 && E % 4 == 0 &&
          ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
            reinterpret_cast<uintptr_t>(d2)) & 15) == 0;
 }

@@ -46,6 +46,7 @@ struct MpaDiag {
   // split-bf16 kernels
   int bfx_r = 0;                     // MPA_BFX_R
   int bfx_wg_s = 0;                  // MPA_BFX_WG_S
+  bool attn_valu = false;            // MPA_ATTN_VALU: head dimension 16 on the VALU kernels instead of the MFMA ones
   // GEMM planner
   int gemm_variant = -1, gemm_splits = 0;   // MPA_GEMM_FORCE="variant,splits"
   // kernel debug switches (honoured by -DMPA_DIAG builds only)
@@ -76,6 +77,7 @@ inline MpaDiag mpa_diag_read() {
   g.tall_off = set("MPA_TALL_OFF");
   g.head_wg_s = num("MPA_HEAD_WG_S", 0);
   g.head_wg_rolled = set("MPA_HEAD_WG_ROLLED");
+  g.attn_valu = set("MPA_ATTN_VALU");
   g.bfx_r = (int)num("MPA_BFX_R", 0);
   g.bfx_wg_s = (int)num("MPA_BFX_WG_S", 0);
   if (const char* e = getenv("MPA_GEMM_FORCE")) {
