@@ -544,8 +544,10 @@ def main():
             "dp_bucket_mb": [round(b["flat"].numel() * 4 / 2 ** 20, 2) for b in averager.buckets] if averager else None,
             "dp_exactness": {"sync_bn": bool(args.sync_bn), "gather_attention": bool(args.gather_attention)},
         }
-        if args.config in TRAIN_GFLOP_PER_PATCH and args.frames == 75:     # the FLOP table is for T = 75 patches
-            step_tflops = TRAIN_GFLOP_PER_PATCH[args.config] * patches_per_s / 1e3
+        from multipitch_architectures_amd.configs import TRAIN_GFLOP_PER_PATCH_T174
+        gflop_table = TRAIN_GFLOP_PER_PATCH if args.frames == 75 else (TRAIN_GFLOP_PER_PATCH_T174 if args.frames == 174 else {})
+        if args.config in gflop_table:                                      # FLOP tables exist for T = 75 and T = 174 patches
+            step_tflops = gflop_table[args.config] * patches_per_s / 1e3
             out["step_tflops"] = step_tflops
             out["step_mfma_frac"] = step_tflops / (PEAK_FP32_MFMA_TFLOPS * world)
             if bfx:

@@ -56,9 +56,19 @@ class GradientAverager:
         # deferred mode: called with the bucket's index right after its gather (on autograd's device thread) -- where
         # `step.TrainStep` cuts its capture
         self.on_bucket = None
-        # reverse registration order ~ order in which autograd produces gradients
+        self.bucket_bytes, self.tail_bytes = int(bucket_bytes), int(tail_bytes)
+        # buckets in reverse registration order first (~ the order in which autograd produces gradients); the first
+        # backward pass records the real arrival order and finish() re-buckets by it once (every rank sees the same
+        # order: same model, same autograd graph), so that bucket k really completes before bucket k+1
+        self._arrival, self._rebucketed = [], False
+        self._build_buckets(list(reversed(self.params)))
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    def _build_buckets(self, ordered):
+        bucket_bytes, tail_bytes = self.bucket_bytes, self.tail_bytes
+        self.buckets, self._owner = [], {}
         plists, cur, cur_bytes = [], [], 0
-        for p in reversed(self.params):
+        for p in ordered:
             nbytes = p.numel() * p.element_size()
             if cur and cur_bytes + nbytes > bucket_bytes:
                 plists.append(cur)
@@ -78,7 +88,6 @@ class GradientAverager:
                 plists.append(tail)
         for pl in plists:
             self._add_bucket(pl)
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
     def _add_bucket(self, plist):
         n = sum(p.numel() for p in plist)
@@ -98,6 +107,8 @@ class GradientAverager:
         self.buckets.append(b)
 
     def _on_grad(self, p):
+        if not self._rebucketed:
+            self._arrival.append(p)
         b = self._owner[p]
         b["pending"] -= 1
         if b["pending"] == 0:
@@ -185,6 +196,23 @@ class GradientAverager:
         self.wait_all()
         self.scale_all()
         self.expose()
+        if not self._rebucketed:
+            self._rebucket()
+
+    def _rebucket(self):
+        """after the first backward pass: buckets in the order the gradients really arrived (parameters that got no
+        gradient go last).  The gradients just exposed are views of the old flat buffers and stay valid; the next step
+        gathers into the new ones."""
+        self._rebucketed = True
+        seen, order = set(), []
+        for p in self._arrival:
+            if id(p) not in seen:
+                seen.add(id(p))
+                order.append(p)
+        order += [p for p in reversed(self.params) if id(p) not in seen]
+        self._arrival = []
+        if [id(p) for b in self.buckets for p in b["params"]] != [id(p) for p in order]:
+            self._build_buckets(order)
 
     @staticmethod
     def _scale(flat, alpha):
