@@ -498,7 +498,7 @@ def main():
         # (scratch/pmc_passes.sh -> scratch/pmc_summary.py -> profiles/); only valid for the configuration they were
         # collected on
         traffic = mfma_busy = traffic_source = None
-        tfiles = ("r03_bf16x3_pmc_traffic.json",) if bfx else ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+        tfiles = ("r03_bf16x3_pmc_traffic.json",) if bfx else ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
         for tname in tfiles:
             tfile = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tfile) and args.config == "SAUnet:L" and B_loc == 256 and args.frames == 75:

@@ -34,14 +34,17 @@ if __name__ == "__main__":
     logging.basicConfig(level=logging.WARNING)
     out = {"task": f"experiments/run_experiment.py --synthetic {NREC} --frames {FRAMES} --epochs {EPOCHS}", "runs": {}}
     for config in (sys.argv[1:] or ["tiny:SAUnet", "tiny:DRCNN"]):
-        a, b = run(config, "f32"), run(config, "bf16x3")
-        a2, b2 = run(config, "f32", seed=4321), run(config, "bf16x3", seed=4321)     # the noise floor: another dropout stream
+        seeds = [1234, 4321, 777, 2024, 99][:int(os.environ.get("AB_SEEDS", "5"))]
+        runs = {prec: [run(config, prec, seed=sd) for sd in seeds] for prec in ("f32", "bf16x3")}
         F = lambda r: r["test"]["f_measure"]
-        out["runs"][config] = {"f32": a, "bf16x3": b, "f32_other_dropout_seed": a2, "bf16x3_other_dropout_seed": b2,
-                               "best_val_loss": {"f32": min(a["val_loss"]), "bf16x3": min(b["val_loss"])},
-                               "f_measure_diff_pp": 100.0 * abs(F(a) - F(b)),
-                               "f_measure_seed_spread_pp": 100.0 * max(abs(F(a) - F(a2)), abs(F(b) - F(b2)))}
-        print(config, "F f32", round(F(a), 4), round(F(a2), 4), "bf16x3", round(F(b), 4), round(F(b2), 4),
-              "best val", round(min(a["val_loss"]), 4), round(min(b["val_loss"]), 4), "epochs", a["epochs"], b["epochs"], flush=True)
+        import statistics as st
+        summ = {prec: {"f_measure": [F(r) for r in rs], "mean": st.mean(F(r) for r in rs),
+                       "stdev": st.stdev(F(r) for r in rs) if len(rs) > 1 else 0.0,
+                       "best_val_loss": [min(r["val_loss"]) for r in rs]} for prec, rs in runs.items()}
+        out["runs"][config] = {"dropout_seeds": seeds, "summary": summ, "runs": runs,
+                               "mean_f_measure_diff_pp": 100.0 * abs(summ["f32"]["mean"] - summ["bf16x3"]["mean"])}
+        print(config, "F f32", [round(v, 3) for v in summ["f32"]["f_measure"]], "mean", round(summ["f32"]["mean"], 4), "+-",
+              round(summ["f32"]["stdev"], 4), "| bf16x3", [round(v, 3) for v in summ["bf16x3"]["f_measure"]], "mean",
+              round(summ["bf16x3"]["mean"], 4), "+-", round(summ["bf16x3"]["stdev"], 4), flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r04_bf16x3_train_ab.json"), "w"), indent=1)

