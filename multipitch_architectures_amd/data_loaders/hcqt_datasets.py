@@ -9,8 +9,11 @@ Differences, all deliberate:
 * Random decisions (EQ parabola, tuning shift, transposition) are drawn on the host from a numpy PCG64 stream, noise by
   a counter-based generator in the kernel -- same distributions as the reference, not the same torch-CPU stream.  Pass
   ``draws=...`` to ``batch`` to dictate them (used by the parity tests).
-* ``'aug:scalingfactor'`` (time scaling, ``dataset_context_segm`` only) and ``'aug:smooth_len'`` are not built:
-  requesting them raises.
+* ``'aug:scalingfactor'`` (time scaling, ``dataset_context_segm`` only) is not built: it resamples every patch to its own
+  random length, so its samples do not stack into a batch; requesting it raises.
+Round 4: ``'aug:smooth_len'`` / ``'aug:smooth_win'`` (target smoothing at construction, :190-194) and the three plain-slicing
+classes ``dataset_context_segm_pitch`` (:292-330), ``dataset_context_segm_widetarget`` (:333-377) and
+``dataset_context_measuresegm`` (:380-436) on the same launch.
 There is no CPU path: construction fails without the HIP library and a GPU.
 """
 import ctypes
@@ -68,9 +71,17 @@ class dataset_context:
         self.noisestd = params.get("aug:noisestd")
         self.tuning = params.get("aug:tuning")
         if self.scalingfactor:
-            raise NotImplementedError("'aug:scalingfactor' (time scaling) is not built")
+            raise NotImplementedError("'aug:scalingfactor' (time scaling) is not built: its patches have random lengths and "
+                                      "do not stack into a batch")
         if params.get("aug:smooth_len", 0) > 1:
-            raise NotImplementedError("'aug:smooth_len' (target smoothing) is not built")
+            if not self._segm:
+                raise NotImplementedError("'aug:smooth_len' belongs to dataset_context_segm (hcqt_datasets.py:190-194)")
+            # one-off at construction, as upstream: the targets convolved along time with a window, scaled to maximum 1
+            from scipy import signal
+            filt = np.expand_dims(signal.get_window(params["aug:smooth_win"], params["aug:smooth_len"] + 1)[1:], axis=1)
+            sm = signal.convolve(np.asarray(torch.as_tensor(targets).cpu()), filt, mode="same")
+            sm /= np.max(sm)
+            self.targets = torch.from_numpy(sm).to(self.device, torch.float32).contiguous()
         if (self.randomeq or self.transposition) and self.inputs.shape[2] != N_BINS:
             raise RuntimeError("the augmentations assume 216 bins (3 per semitone), as the reference does")
         if self.transposition and self.transposition > 5:
@@ -136,6 +147,81 @@ class dataset_context:
 class dataset_context_segm(dataset_context):
     """``dataset_context_segm`` (hcqt_datasets.py:144-289) without time scaling: ``seglength`` target frames per patch."""
     _segm = True
+
+
+class dataset_context_segm_pitch(dataset_context_segm):
+    """``dataset_context_segm_pitch`` (hcqt_datasets.py:292-330): segments without augmentation whose targets are columns
+    24..95 of a 128-pitch roll.  The columns are cut once at construction (a resident (T,72) tensor)."""
+
+    def __init__(self, inputs, targets, params, device="cuda:0", seed=0):
+        t = torch.as_tensor(targets)
+        if t.dim() != 2 or t.shape[1] < 96:
+            raise RuntimeError(f"dataset_context_segm_pitch: targets must be (T, >= 96) pitch rolls, got {tuple(t.shape)}")
+        keep = {k: params[k] for k in ("context", "seglength", "stride", "compression")}
+        super().__init__(inputs, t[:, 24:96], keep, device=device, seed=seed)
+
+
+class dataset_context_segm_widetarget(dataset_context_segm):
+    """``dataset_context_segm_widetarget`` (hcqt_datasets.py:333-377): `seglength` target frames, and around their centre an
+    input window of 500 frames + context (no augmentation).  Indices whose window leaves the recording raise IndexError
+    (upstream a negative slice start silently yields a wrong-sized tensor)."""
+    SEGL_HCQT = 500
+
+    def __init__(self, inputs, targets, params, device="cuda:0", seed=0):
+        keep = {k: params[k] for k in ("context", "seglength", "stride", "compression")}
+        super().__init__(inputs, targets, keep, device=device, seed=seed)
+        self.frames = 2 * (self.context // 2) + self.SEGL_HCQT
+        self.desc = L.ContextDesc(self.inputs.shape[0], self.inputs.shape[2], self.frames, self.targets.shape[1],
+                                  self.seglength, self.desc.flags, float(self.compression or 0.0), 0.0)
+
+    def addresses(self, indices):
+        idx = np.asarray(indices, dtype=np.int64).reshape(-1)
+        index = idx * self.stride + self.context // 2
+        x0 = index + self.seglength // 2 - self.SEGL_HCQT // 2 - self.context // 2
+        if idx.size and (idx.min() < 0 or x0.min() < 0 or x0.max() + self.frames > self.inputs.shape[1] or
+                         index.max() + self.seglength > self.targets.shape[0]):
+            raise IndexError("patch window outside the recording")
+        src = self.inputs.data_ptr() + x0 * (self.inputs.shape[2] * 4)
+        tgt = self.targets.data_ptr() + index * (self.targets.shape[1] * 4)
+        cs = np.full(idx.shape, self.inputs.shape[1] * self.inputs.shape[2], dtype=np.int64)
+        return src.astype(np.uint64), cs, tgt.astype(np.uint64)
+
+
+class dataset_context_measuresegm(dataset_context_segm):
+    """``dataset_context_measuresegm`` (hcqt_datasets.py:380-436): segments bounded by given measure positions (frame
+    indices); `seglength` and `stride` count measures.  Segments have different lengths, so items are served one by one
+    (``ds[i]``; upstream a DataLoader can only batch them with batch_size 1 as well)."""
+
+    def __init__(self, inputs, targets, measures, params, device="cuda:0", seed=0):
+        keep = {k: params[k] for k in ("context", "seglength", "stride", "compression")}
+        self._measure_seglength = keep["seglength"]
+        super().__init__(inputs, targets, dict(keep, seglength=1), device=device, seed=seed)
+        self.measures = np.asarray(torch.as_tensor(measures).cpu()).astype(np.float64).reshape(-1)
+
+    def __len__(self):
+        return (self.measures.size - self._measure_seglength - 1) // self.stride     # :416-418
+
+    def batch(self, indices, draws=None):
+        idx = np.asarray(indices).reshape(-1)
+        if idx.size != 1:
+            raise RuntimeError("dataset_context_measuresegm serves one segment per call: their lengths differ")
+        i = int(idx[0]) * self.stride
+        start, end = int(self.measures[i]), int(self.measures[i + self._measure_seglength])
+        hc = self.context // 2
+        if i < 0 or end <= start or start - hc < 0 or end + hc > self.inputs.shape[1]:
+            raise IndexError("measure segment (with its context) outside the recording")
+        self.seglength, self.frames = end - start, end - start + 2 * hc
+        self.desc = L.ContextDesc(self.inputs.shape[0], self.inputs.shape[2], self.frames, self.targets.shape[1],
+                                  self.seglength, self.desc.flags, float(self.compression or 0.0), 0.0)
+        self._start = start
+        return gather([(self, idx)])
+
+    def addresses(self, indices):
+        hc = self.context // 2
+        src = np.array([self.inputs.data_ptr() + (self._start - hc) * (self.inputs.shape[2] * 4)], dtype=np.uint64)
+        tgt = np.array([self.targets.data_ptr() + self._start * (self.targets.shape[1] * 4)], dtype=np.uint64)
+        cs = np.array([self.inputs.shape[1] * self.inputs.shape[2]], dtype=np.int64)
+        return src, cs, tgt
 
 
 def gather(parts, draws=None):

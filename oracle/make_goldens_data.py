@@ -29,7 +29,8 @@ _tv.transforms = types.ModuleType("torchvision.transforms")
 sys.modules.setdefault("torchvision", _tv)
 sys.modules.setdefault("torchvision.transforms", _tv.transforms)
 
-from libdl.data_loaders.hcqt_datasets import dataset_context, dataset_context_segm  # noqa: E402  (the reference)
+from libdl.data_loaders.hcqt_datasets import (dataset_context, dataset_context_measuresegm, dataset_context_segm,  # noqa: E402
+                                              dataset_context_segm_pitch, dataset_context_segm_widetarget)  # (the reference)
 
 from multipitch_architectures_amd.synth import synth_file  # noqa: E402
 
@@ -53,8 +54,44 @@ CASES = [("val", VAL, 72, [(0, 0), (3, 0)]),
           72, [(i, 700 + i) for i in range(6)])]
 
 
+# round 4: the plain-slicing classes and the target smoothing (no random decisions: compared with the reference's output
+# directly, tests/test_gpu_data.py::test_slicing_dataset_variants).  (name, class, params, n_out of the synthetic file,
+# frames of the file, indices); dataset_context_measuresegm also gets the measure positions below.
+MEASURES = [40, 77, 118, 160, 197, 241, 280, 326, 371, 410, 452, 499, 540, 577]
+VARIANTS = [("xsegm_pitch", "dataset_context_segm_pitch", {"context": 75, "seglength": 50, "stride": 30, "compression": 10}, 128, 400, [0, 3, 7]),
+            ("xsegm_widetarget", "dataset_context_segm_widetarget", {"context": 75, "seglength": 100, "stride": 40, "compression": 10}, 72, 900,
+             [5, 6, 8]),
+            ("xmeasuresegm", "dataset_context_measuresegm", {"context": 75, "seglength": 2, "stride": 3, "compression": 10}, 72, 700, [0, 1, 3]),
+            ("xsegm_smooth", "dataset_context_segm", {"context": 75, "seglength": 60, "stride": 45, "compression": 10,
+                                                      "aug:smooth_len": 6, "aug:smooth_win": "hann"}, 72, 400, [0, 2, 5])]
+
+
+def variants():
+    classes = {"dataset_context_segm_pitch": dataset_context_segm_pitch, "dataset_context_segm_widetarget": dataset_context_segm_widetarget,
+               "dataset_context_measuresegm": dataset_context_measuresegm, "dataset_context_segm": dataset_context_segm}
+    for name, cls_name, params, n_out, frames, indices in VARIANTS:
+        inputs, targets = synth_file(frames=frames, n_bins_out=n_out, seed=78)
+        args = (torch.from_numpy(inputs.copy()), torch.from_numpy(targets.copy()))
+        if cls_name == "dataset_context_measuresegm":
+            args += (torch.tensor(MEASURES),)
+        ds = classes[cls_name](*args, dict(params))
+        out = {"params": np.array(json.dumps(params)), "cls": np.array(cls_name), "n_out": np.array(n_out), "frames": np.array(frames),
+               "indices": np.array(indices, dtype=np.int64), "len": np.array(len(ds)), "measures": np.array(MEASURES, dtype=np.int64)}
+        for k, index in enumerate(indices):
+            X, y = ds[index]
+            X = np.asarray(X, dtype=np.float32)
+            out[f"{k}.shape"] = np.array(X.shape)
+            out[f"{k}.xs"] = X.ravel()[::11].copy()
+            out[f"{k}.stats"] = np.array([X.astype(np.float64).sum(), np.abs(X).astype(np.float64).sum(), X.max()])
+            out[f"{k}.y"] = np.asarray(y, dtype=np.float32)
+        np.savez_compressed(os.path.join(GOLDEN_DIR, f"data{name}.npz"), **out)
+        print("wrote", name, len(indices), "items; len(ds) =", len(ds), "X", out["0.shape"], "y", out["0.y"].shape)
+
+
 def main():
     os.makedirs(GOLDEN_DIR, exist_ok=True)
+    if "--variants" in sys.argv:
+        return variants()
     for name, params, n_out, items in CASES:
         inputs, targets = synth_file(frames=400, n_bins_out=n_out, seed=77)
         cls = dataset_context_segm if "seglength" in params else dataset_context

@@ -117,3 +117,37 @@ def test_context_rejects_bad_requests():
         dataset_context(inputs, targets, {"context": 75, "stride": 10, "compression": 10, "aug:scalingfactor": 1.2})
     X, y = ds[0]
     assert tuple(X.shape) == (6, 75, 216) and tuple(y.shape) == (1, 1, 72)
+
+
+VARIANT_FILES = sorted(glob.glob(os.path.join(GOLDEN, "datax*.npz")))
+
+
+@pytest.mark.parametrize("path", VARIANT_FILES, ids=[os.path.basename(f)[5:-4] for f in VARIANT_FILES])
+def test_slicing_dataset_variants(path):
+    """dataset_context_segm_pitch / _widetarget / dataset_context_measuresegm (hcqt_datasets.py:292-436) and the target smoothing of
+    dataset_context_segm ('aug:smooth_len', :190-194): no random decisions, so the HIP classes are compared with the reference
+    classes' own output (oracle/make_goldens_data.py --variants): len(), X (strided sample + sums, logf vs np.log: 1-2 ulp), y"""
+    from multipitch_architectures_amd import data_loaders as DL
+    g = np.load(path)
+    params, cls_name = json.loads(str(g["params"])), str(g["cls"])
+    inputs, targets = synth_file(frames=int(g["frames"]), n_bins_out=int(g["n_out"]), seed=78)
+    args = (inputs, targets) + ((g["measures"],) if cls_name == "dataset_context_measuresegm" else ())
+    ds = getattr(DL, cls_name)(*args, dict(params))
+    assert len(ds) == int(g["len"])
+    for k, index in enumerate(g["indices"]):
+        X, y = ds[int(index)]
+        X, y = X.cpu().numpy(), y.cpu().numpy()
+        assert list(X.shape) == list(g[f"{k}.shape"]) and y.shape == g[f"{k}.y"].shape
+        np.testing.assert_allclose(X.ravel()[::11], g[f"{k}.xs"], rtol=5e-7, atol=2e-9)
+        s = g[f"{k}.stats"]
+        np.testing.assert_allclose([X.astype(np.float64).sum(), np.abs(X).astype(np.float64).sum(), X.max()], s, rtol=1e-6)
+        if "aug:smooth_len" in params:       # smoothed targets: float64 convolution cast to float32 on both sides
+            np.testing.assert_allclose(y, g[f"{k}.y"], rtol=1e-6, atol=1e-7)
+        else:
+            np.testing.assert_array_equal(y, g[f"{k}.y"])
+    if cls_name != "dataset_context_measuresegm":           # batches of equal-length segments stack
+        Xb, yb = ds.batch([int(i) for i in g["indices"]])
+        assert Xb.shape[0] == len(g["indices"]) and torch.equal(Xb[1], ds[int(g["indices"][1])][0])
+    else:
+        with pytest.raises(RuntimeError):
+            ds.batch([0, 1])
