@@ -267,7 +267,7 @@ class _UNetTrunk(nn.Module):
         plain = not (torch.is_grad_enabled() and x.requires_grad and len(stage) == 2 and type(pool) is MaxPool2d)
         for m in (stage, pool):
             plain = plain or bool(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks)
-        if plain or ops._NO_POOLSKIP:
+        if plain:
             return stage(x), x
         y, skip = ops.pool_skip(x, pool.kernel_size, pool.stride, pool.padding)
         return stage[1](y), skip

@@ -801,11 +801,6 @@ def pool_skip(x, kernel, stride=None, padding=(0, 0)):
     return y, skip
 
 
-import os as _os
-_NO_FANOUT = _os.environ.get("MPA_NO_FANOUT", "0") == "1"          # diagnostics: autograd's own accumulation (ATen add)
-_NO_POOLSKIP = _os.environ.get("MPA_NO_POOLSKIP", "0") == "1"      # diagnostics: separate pool / skip gradients
-
-
 class FanoutFn(torch.autograd.Function):
     """x -> (x, x) for a tensor with two consumers (the transformer layer's residual branches, unet_cnns.py:156-158; the CNN
     family's residual stages): the two gradients are added by mpa_add here instead of by autograd's accumulation, which
@@ -827,7 +822,7 @@ class FanoutFn(torch.autograd.Function):
 
 
 def fanout(x):
-    if not (torch.is_grad_enabled() and x.requires_grad) or _NO_FANOUT:
+    if not (torch.is_grad_enabled() and x.requires_grad):
         return x, x
     return FanoutFn.apply(x)
 
