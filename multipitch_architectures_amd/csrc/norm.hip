@@ -552,6 +552,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
 }
 
+// the partial pairs of bn_bwd_stats_kernel<V, true> summed once per channel (one wave per channel, same butterfly order as
+// the in-kernel sum of bn_bwd_apply_kernel): for tensors whose apply launch has so many workgroups that each of them
+// re-adding the 64 pairs costs more than this 5-us launch
+__global__ __launch_bounds__(64) void bn_bwd_sum_partials_kernel(const double* __restrict__ part, int nsplit,
+                                                                 double* __restrict__ stats) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  const double* pp = part + ((long)c * nsplit + (lane < nsplit ? lane : 0)) * 2;
+  const double s1 = mpa_wave_sum_d(lane < nsplit ? pp[0] : 0.0);
+  const double s2 = mpa_wave_sum_d(lane < nsplit ? pp[1] : 0.0);
+  if (lane == 0) { stats[2 * c] = s1; stats[2 * c + 1] = s2; }
+}
+
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ stats, float* dgamma, float* dbeta, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
@@ -560,6 +572,7 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ stats, float* 
 }
 
 #define MPA_BN_BWD_SPLITS 64      // partial pairs per channel bn_bwd_apply_kernel sums (one per lane)
+#define MPA_BN_BWD_INLINE_BLOCKS 8192   // apply launches with more workgroups than this get the pairs summed by a launch of its own
 inline int stat_splits(int B, int C, int HW) {
   long per = (long)B * HW;
   long want = std::max<long>(1, (256L * 16) / C);
@@ -697,14 +710,24 @@ int mpa_bn_relu_bwd(const float* dy, const float* x, const float* y, const float
   hipStream_t s = (hipStream_t)stream;
   if ((long)B * HW > 0x7fffffffL) return MPA_ERR_ARG;
   // two launches, no zero-fill: at most MPA_BN_BWD_SPLITS partial pairs per channel, summed by the apply kernel's waves
-  const int splits = std::min(stat_splits(B, C, HW), MPA_BN_BWD_SPLITS);
+  const int chunks = (int)std::max<long>(1, std::min<long>(mpa_cdiv(HW, 1024), 64));
+  // many apply workgroups: the pairs are summed once by a launch of its own (into the last 2 C doubles of the workspace,
+  // which the partials of at most 63 splits leave free) instead of once per apply workgroup
+  const bool big = (long)B * C * chunks > MPA_BN_BWD_INLINE_BLOCKS;
+  const int splits = std::min(stat_splits(B, C, HW), big ? MPA_BN_BWD_SPLITS - 1 : MPA_BN_BWD_SPLITS);
   const bool vec = HW % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) |
                                     reinterpret_cast<uintptr_t>(y)) & 15) == 0;
   if (vec) MPA_LAUNCH((bn_bwd_stats_kernel<4, true>), dim3(splits, C), dim3(256), 0, s, dy, x, y, gamma, beta, save_mean,
                       save_invstd, stats_ws, B, C, HW, relu);
   else MPA_LAUNCH((bn_bwd_stats_kernel<1, true>), dim3(splits, C), dim3(256), 0, s, dy, x, y, gamma, beta, save_mean, save_invstd,
                   stats_ws, B, C, HW, relu);
-  const int chunks = (int)std::max<long>(1, std::min<long>(mpa_cdiv(HW, 1024), 64));
+  if (big) {
+    double* sums = stats_ws + (long)2 * C * (MPA_BN_BWD_SPLITS - 1);
+    MPA_LAUNCH(bn_bwd_sum_partials_kernel, dim3(C), dim3(64), 0, s, (const double*)stats_ws, splits, sums);
+    MPA_LAUNCH(bn_bwd_apply_kernel, dim3(B * C, chunks), dim3(256), 0, s, dy, x, y, gamma, beta, save_mean, save_invstd,
+               (const double*)sums, dx, C, HW, (double)B * HW, relu, train, dgamma, dbeta, 0);
+    return mpa_launch_status();
+  }
   MPA_LAUNCH(bn_bwd_apply_kernel, dim3(B * C, chunks), dim3(256), 0, s, dy, x, y, gamma, beta, save_mean, save_invstd,
                      (const double*)stats_ws, dx, C, HW, (double)B * HW, relu, train, dgamma, dbeta, splits);
   return mpa_launch_status();
