@@ -296,11 +296,13 @@ int gemm_impl(GemmParams p, int nbatch, int shared_c, hipStream_t s) {
   // LDS operand read per MFMA, the 128x128 tile one per two).  Splitting K (atomic accumulation, no activation, order
   // of the fp32 adds not fixed) is what keeps the big tile usable for tall-skinny products such as the MLP's second
   // layer (13312x128x8192) and the weight gradients (K = batch*positions).
-  static const int TM[4] = {128, 128, 64, 64}, TN[4] = {128, 64, 128, 64};
-  static const double EFF[4] = {1.0, 0.8, 0.8, 0.55};
+  // (variant 4, 32x32 tiles: the projections of the attention layers at small local batches -- 1664 x 128 x 128 is 52 tiles of
+  // 64x64 on 256 CUs and pure latency, ~12 us per launch; as 208 tiles of 32x32 each workgroup has a quarter of the chain)
+  static const int TM[5] = {128, 128, 64, 64, 32}, TN[5] = {128, 64, 128, 64, 32};
+  static const double EFF[5] = {1.0, 0.8, 0.8, 0.55, 0.3};
   int variant = 3, splits = 1;
   double best = 1e300;
-  for (int v = 0; v < 4; ++v) {
+  for (int v = 0; v < 5; ++v) {
     const long blocks = mpa_cdiv(M, TM[v]) * mpa_cdiv(N, TN[v]);
     // padding waste of partial tiles is paid in full
     for (int sp = 1; sp <= 32; ++sp) {             // every split count: 72 tiles x 7 splits fill 504 of 512 slots, x 8 need two rounds
@@ -312,7 +314,7 @@ int gemm_impl(GemmParams p, int nbatch, int shared_c, hipStream_t s) {
   }
   if (mpa_diag().gemm_variant >= 0) {            // diagnostics: MPA_GEMM_FORCE="variant,splits"
     const int fv = mpa_diag().gemm_variant, fs = mpa_diag().gemm_splits;
-    if (fv >= 0 && fv < 4 && fs >= 1 && fs <= 32 && (fs == 1 || act == MPA_ACT_NONE)) {
+    if (fv >= 0 && fv < 5 && fs >= 1 && fs <= 32 && (fs == 1 || act == MPA_ACT_NONE)) {
       variant = fv; splits = fs;
     }
   }
@@ -330,6 +332,7 @@ int gemm_impl(GemmParams p, int nbatch, int shared_c, hipStream_t s) {
     case 0: launch_gemm<4, 4>(p, splits, s); break;
     case 1: launch_gemm<4, 2>(p, splits, s); break;
     case 2: launch_gemm<2, 4>(p, splits, s); break;
+    case 4: launch_gemm<1, 1>(p, splits, s); break;
     default: launch_gemm<2, 2>(p, splits, s); break;
   }
   return mpa_launch_status();
