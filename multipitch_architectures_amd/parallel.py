@@ -107,7 +107,7 @@ class GradientAverager:
         self.buckets.append(b)
 
     def _on_grad(self, p):
-        if not self._rebucketed:
+        if not self._rebucketed and len(self._arrival) < len(self.params):     # (the first backward pass only)
             self._arrival.append(p)
         b = self._owner[p]
         b["pending"] -= 1
