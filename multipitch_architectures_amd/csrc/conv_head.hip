@@ -261,25 +261,28 @@ __global__ __launch_bounds__(WM * WN * 64) void head_gemm_kernel(const HeadParam
   if constexpr (FWD) {
     // forward (and the tall filters): every 16 x 16 accumulator tile through a wave-private LDS patch so that a lane owns 4
     // consecutive pixels of one output row and writes one 16-byte store (25-35 per lane instead of 100-140 4-byte ones)
+    // Bias and activation are applied in the accumulator layout, from bias values fetched before the barrier: a load that is
+    // first used inside the divergent store blocks is waited for in every one of them (vmcnt(0): one in-order counter for
+    // loads and stores), which made each store wait for the one before it.
+    float bs[MT][4];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bs[t][r] = p.bias ? p.bias[min((wm * MT + t) * 16 + 4 * g + r, p.Mrows - 1)] : 0.f;
     __syncthreads();                                  // the main loop's LDS images are dead now
     float* patch = hlds + wave * (16 * 20);           // [row 16][pixel 16 (+4 pad)]
     const int rl = lane >> 2, quad = lane & 3;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       const int m = (wm * MT + t) * 16 + rl;
-      const float bs = (p.bias && m < p.Mrows) ? p.bias[m] : 0.f;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) patch[(4 * g + r) * 20 + j] = acc[t][nb][r];
+        for (int r = 0; r < 4; ++r) patch[(4 * g + r) * 20 + j] = mpa_apply_act(acc[t][nb][r] + bs[t][r], p.act, p.slope);
         const float4 v = *reinterpret_cast<const float4*>(patch + rl * 20 + 4 * quad);
         const int px = p0 + (wn * NB + nb) * 16 + 4 * quad;
-        if (m < p.Mrows && px < p.P) {                // (P % 4 == 0: a quad is inside or outside as a whole)
-          float4 o;
-          o.x = mpa_apply_act(v.x + bs, p.act, p.slope); o.y = mpa_apply_act(v.y + bs, p.act, p.slope);
-          o.z = mpa_apply_act(v.z + bs, p.act, p.slope); o.w = mpa_apply_act(v.w + bs, p.act, p.slope);
-          *reinterpret_cast<float4*>(ob + (long)m * p.P + px) = o;
-        }
+        if (m < p.Mrows && px < p.P)                  // (P % 4 == 0: a quad is inside or outside as a whole)
+          *reinterpret_cast<float4*>(ob + (long)m * p.P + px) = v;
       }
     }
     return;

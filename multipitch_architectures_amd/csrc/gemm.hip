@@ -218,9 +218,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pp) {
   // the scalar path writes 64-byte segments per row, which the memory system handles at a fraction of its store rate
   // (the MLP's 13312 x 8192 outputs were bound by it).
   constexpr int PW = WN * 16 + 4;                       // patch row pitch (floats)
-  const bool wide = !splitk && (p.ldc & 3) == 0 && (p.N & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 &&
-                    (!p.bias || (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0);
+  const bool wide = !splitk && (p.ldc & 3) == 0 && (p.N & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
   if (wide) {
+    // (bias in the accumulator layout, fetched before the barrier and added in registers: a load first used inside the
+    // divergent store blocks below is waited for in each of them, vmcnt(0), i.e. every store waits for the one before it)
+    float bj[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) bj[j] = p.bias ? p.bias[min(n0 + wn + j * 16 + l16, p.N - 1)] : 0.f;
     __syncthreads();                                    // operand images are dead
     static_assert(AF >= 4 * 16 * PW || BF >= 4 * 16 * PW, "epilogue patches must fit one operand image");
     float* patch = (AF >= 4 * 16 * PW ? As : Bs) + wave * (16 * PW);   // 4 waves x 16 x PW floats
@@ -233,11 +237,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pp) {
 #pragma unroll
       for (int j = 0; j < WN; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) patch[(kq * 4 + r) * PW + j * 16 + l16] = acc[i][j][r];
+        for (int r = 0; r < 4; ++r) patch[(kq * 4 + r) * PW + j * 16 + l16] = acc[i][j][r] + bj[j];
       __builtin_amdgcn_wave_barrier();
       if (n < p.N) {
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n);
 #pragma unroll
         for (int q = 0; q < 16 / RPI; ++q) {
           const int row = q * RPI + rr;
@@ -245,7 +247,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pp) {
           if (m < p.M) {
             float4 v = *reinterpret_cast<const float4*>(patch + row * PW + c4 * 4);
             float* c = p.C + (long)m * p.ldc + n;
-            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
             if (p.accumulate) {
               const float4 o = *reinterpret_cast<const float4*>(c);
               v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
@@ -280,6 +281,192 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pp) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ short-K panel kernel
+// C[M,N] = act(A[M,K] B[K,N] + bias) for K = 16 G <= 128 with N large: the transformer MLP's first layer and the input gradient
+// of its second one (13312 x 8192 x 128 at batch 256: unet_cnns.py:137-141).  In gemm_kernel these products are four k tiles
+// long, so the exposed prologue and the 64 KB epilogue of every 128 x 128 tile cost as much as its MFMAs (71-77 TFLOP/s,
+// mfma_busy 0.49).  Here a workgroup keeps its 128-row panel of A *in registers* for its whole life -- a wave's 32 rows x K as
+// G float4 per row tile and lane, in the contraction layout (kq, j) -> 4 kq + j of a 16-wide k group, so that one register
+// quad feeds four k steps -- and walks its share of the columns in 64-wide tiles: the B tile (64 x K, row-major with a pitch
+// of 33 16-byte slots: b128 reads with one 2-way conflict per lane group) is the only operand staged through LDS, prefetched
+// into registers behind the MFMAs of the previous tile; 4 b128 operand reads per 32 MFMAs; the epilogue goes through a
+// wave-private LDS patch as 16-byte stores, as in gemm_kernel.  BNC: B is n-contiguous (B[k][n], 4 x 4 register transposes
+// while staging) instead of k-contiguous (B[n][k]).
+constexpr int PN = 64;                         // columns per tile
+constexpr int PBP = 132;                       // floats per B row in LDS (33 slots)
+
+// B tile staging of the panel kernel: 64 columns x K through registers, NV float4 per thread
+template <int G, bool BNC>
+__device__ __forceinline__ void panel_load_b(f32x4 (&rb)[PN * 16 * G / 4 / 256], const GemmParams& p, int n0, int tid, int bn4,
+                                             int bkk) {
+  constexpr int K = 16 * G, NV = PN * K / 4 / 256;
+  if (!BNC) {                                        // B[n][k]: a row's K floats are contiguous: K/4 threads per row
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int e = u * 256 + tid;
+      const int nl = e / (K / 4), q = e % (K / 4);
+      rb[u] = *reinterpret_cast<const f32x4*>(p.B + (long)min(n0 + nl, p.N - 1) * p.ldb_n + 4 * q);
+    }
+  } else {                                           // B[k][n]: a thread takes 4 consecutive n of the rows k = 64 h + 4 kk + c
+    const float* b = p.B + (long)(4 * bkk) * p.ldb_k + min(n0 + 4 * bn4, p.N - 4);
+#pragma unroll
+    for (int u = 0; u < NV; ++u) rb[u] = *reinterpret_cast<const f32x4*>(b + (long)(64 * (u >> 2) + (u & 3)) * p.ldb_k);
+  }
+}
+
+template <int G, bool BNC>
+__device__ __forceinline__ void panel_store_b(const f32x4 (&rb)[PN * 16 * G / 4 / 256], float* Bs, int tid, int bn4, int bkk) {
+  constexpr int K = 16 * G, NV = PN * K / 4 / 256;
+  if (!BNC) {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int e = u * 256 + tid;
+      const int nl = e / (K / 4), q = e % (K / 4);
+      *reinterpret_cast<f32x4*>(Bs + nl * PBP + 4 * q) = rb[u];
+    }
+  } else {
+    // 4 x 4 register transposes: (4 k) x (4 n) -> per n one float4 along k; the lane order (bn4, bkk) makes the b128 stores
+    // of a 16-lane group hit 16 different slots mod 16
+#pragma unroll
+    for (int h = 0; h < NV / 4; ++h) {
+      float* d = Bs + (4 * bn4) * PBP + 64 * h + 4 * bkk;
+      *reinterpret_cast<f32x4*>(d) = f32x4{rb[4 * h].x, rb[4 * h + 1].x, rb[4 * h + 2].x, rb[4 * h + 3].x};
+      *reinterpret_cast<f32x4*>(d + PBP) = f32x4{rb[4 * h].y, rb[4 * h + 1].y, rb[4 * h + 2].y, rb[4 * h + 3].y};
+      *reinterpret_cast<f32x4*>(d + 2 * PBP) = f32x4{rb[4 * h].z, rb[4 * h + 1].z, rb[4 * h + 2].z, rb[4 * h + 3].z};
+      *reinterpret_cast<f32x4*>(d + 3 * PBP) = f32x4{rb[4 * h].w, rb[4 * h + 1].w, rb[4 * h + 2].w, rb[4 * h + 3].w};
+    }
+  }
+}
+
+template <int G, bool BNC>
+__global__ __launch_bounds__(256) void gemm_panel_kernel(const GemmParams p, int cols_per_wg) {
+  constexpr int K = 16 * G;
+  __shared__ __attribute__((aligned(16))) float Bs[PN * PBP];
+  __shared__ __attribute__((aligned(16))) float patch_all[4 * 16 * (PN + 4)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kq = lane >> 4, l16 = lane & 15;
+  const int m0 = blockIdx.y * 128 + wave * 32;
+  const int nbeg = blockIdx.x * cols_per_wg, nend = min(p.N, nbeg + cols_per_wg);
+  // Rows past M and columns past N are loaded from clamped addresses and never stored: an element of C depends on its own
+  // row of A and column of B only, so no masking of the operands (a select on a loaded value would make the wave wait for the
+  // load where it is issued and undo the prefetch).
+  // the wave's A panel: rows m0 + 16 i + l16, k = 16 s + 4 kq + (0..3)
+  f32x4 a[2][G];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = m0 + i * 16 + l16;
+    const float* ar = p.A + (long)min(row, p.M - 1) * p.lda_m + 4 * kq;
+#pragma unroll
+    for (int sg = 0; sg < G; ++sg) {
+      a[i][sg] = *reinterpret_cast<const f32x4*>(ar + 16 * sg);
+    }
+  }
+  // B tile staging: 64 rows (n) x K; per thread NV float4
+  constexpr int NV = PN * K / 4 / 256;
+  f32x4 rb[NV];
+  const int bn4 = 4 * (lane >> 4) + (lane & 3), bkk = 4 * wave + ((lane >> 2) & 3);   // n-contiguous B: 16 n quads x 16 k quads
+  panel_load_b<G, BNC>(rb, p, nbeg, tid, bn4, bkk);
+  float* patch = patch_all + wave * 16 * (PN + 4);
+  constexpr int PW = PN + 4;
+  const bool has_bias = p.bias != nullptr, relu = p.act == MPA_ACT_RELU;
+  panel_store_b<G, BNC>(rb, Bs, tid, bn4, bkk);
+  __syncthreads();
+  for (int n0 = nbeg; n0 < nend; n0 += PN) {
+    // next tile's loads fly behind this tile's MFMAs (the last pass re-reads the last columns); the bias of the epilogue too
+    panel_load_b<G, BNC>(rb, p, min(n0 + PN, nend - 4), tid, bn4, bkk);
+    // (in the accumulator layout -- one column per lane and j -- so that bias and activation are applied in registers and
+    // the conditional stores below carry no pending load: a wait inside a divergent block is re-issued in every block)
+    float bj[4] = {0.f, 0.f, 0.f, 0.f};
+    if (has_bias) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bj[j] = p.bias[min(n0 + j * 16 + l16, p.N - 1)];
+    }
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sg = 0; sg < G; ++sg) {
+      f32x4 b4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b4[j] = *reinterpret_cast<const f32x4*>(Bs + (j * 16 + l16) * PBP + 16 * sg + 4 * kq);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][sg].x, b4[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][sg].y, b4[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][sg].z, b4[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][sg].w, b4[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    // The next B tile goes to LDS *before* this tile's stores are issued: the wait for its registers would otherwise also
+    // wait for the stores (one in-order counter for loads and stores), and the stores now drain behind the next tile's MFMAs.
+    __builtin_amdgcn_sched_barrier(0);                 // (keeps the staging's register moves, and their wait, below the MFMAs)
+    __syncthreads();                                   // every wave is done with this B tile
+    panel_store_b<G, BNC>(rb, Bs, tid, bn4, bkk);
+    // epilogue: each 16-row slab of the wave tile through the wave's LDS patch, then 16 lanes x float4 per row
+    constexpr int C4 = PN / 4;                         // 16 float4 per row: 4 rows per store instruction
+    const int c4 = lane % C4, rr = lane / C4;
+    const int n = n0 + c4 * 4;
+    const bool interior = m0 + 32 <= p.M && n0 + PN <= p.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[i][j][r] + bj[j];
+          patch[(kq * 4 + r) * PW + j * 16 + l16] = (relu && !(v > 0.f)) ? 0.f : v;      // = mpa_apply_act for NONE / RELU
+        }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = q * 4 + rr;
+        const int m = m0 + i * 16 + row;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(patch + row * PW + c4 * 4);
+        float* dst = p.C + (long)m * p.ldc + n;
+        if (interior) *reinterpret_cast<f32x4*>(dst) = v;               // wave-uniform: no divergence on the common path
+        else if (m < p.M && n + 3 < p.N) *reinterpret_cast<f32x4*>(dst) = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();                                   // the next B tile is in place
+  }
+}
+
+// does the panel kernel take this product?  (single product, plain store, K = 64 / 128, A k-contiguous, B contiguous along k or
+// n, everything 16-byte aligned, N a multiple of 4 and wide enough to amortise the panel load)
+inline bool panel_ok(const GemmParams& p, int nbatch, int shared_c) {
+  auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (nbatch != 1 || shared_c || p.accumulate || (p.K != 128 && p.K != 64) || p.lda_k != 1 || p.lda_m % 4) return false;
+  const bool bk = p.ldb_k == 1 && p.ldb_n % 4 == 0, bn = p.ldb_n == 1 && p.ldb_k % 4 == 0;
+  if (!(bk || bn) || p.N % 4 || p.N < 1024 || p.M < 256 || p.ldc % 4) return false;
+  if (p.act != MPA_ACT_NONE && p.act != MPA_ACT_RELU) return false;
+  return al(p.A) && al(p.B) && al(p.C) && (!p.bias || al(p.bias)) && !mpa_diag().gemm_no_panel;
+}
+
+int launch_panel(const GemmParams& p, hipStream_t s) {
+  const long mt = mpa_cdiv(p.M, 128), nt = mpa_cdiv(p.N, PN);
+  // ~3 workgroups per CU in flight, whole column tiles per workgroup
+  const long want = mpa_diag().gemm_panel_wgs > 0 ? mpa_diag().gemm_panel_wgs : 768;
+  long nsplit = std::max<long>(1, std::min<long>(nt, mpa_cdiv(want, mt)));
+  const int cols = (int)(mpa_cdiv(nt, nsplit) * PN);
+  nsplit = mpa_cdiv(p.N, cols);
+  const dim3 grid((unsigned)nsplit, (unsigned)mt);
+  const bool bnc = p.ldb_n == 1 && p.ldb_k != 1;
+  if (p.K == 128) {
+    if (bnc) MPA_LAUNCH((gemm_panel_kernel<8, true>), grid, dim3(256), 0, s, p, cols);
+    else MPA_LAUNCH((gemm_panel_kernel<8, false>), grid, dim3(256), 0, s, p, cols);
+  } else {
+    if (bnc) MPA_LAUNCH((gemm_panel_kernel<4, true>), grid, dim3(256), 0, s, p, cols);
+    else MPA_LAUNCH((gemm_panel_kernel<4, false>), grid, dim3(256), 0, s, p, cols);
+  }
+  return mpa_launch_status();
+}
+
 template <int WM, int WN>
 void launch_gemm(const GemmParams& p, int splits, hipStream_t s) {
   dim3 grid((unsigned)mpa_cdiv(p.N, 2 * WN * 16), (unsigned)mpa_cdiv(p.M, 2 * WM * 16),
@@ -291,6 +478,7 @@ int gemm_impl(GemmParams p, int nbatch, int shared_c, hipStream_t s) {
   const int M = p.M, N = p.N, K = p.K, act = p.act, accumulate = p.accumulate;
   const long ldc = p.ldc;
   float* C = p.C;
+  if (panel_ok(p, nbatch, shared_c)) return launch_panel(p, s);
   // Pick tile and K-split by a small cost model: whole "rounds" of workgroups over 256 CUs x 2 resident workgroups,
   // each costing (its K extent + a fixed prologue/epilogue) x tile area / tile efficiency (the 64-wide tiles issue one
   // LDS operand read per MFMA, the 128x128 tile one per two).  Splitting K (atomic accumulation, no activation, order

@@ -49,6 +49,8 @@ struct MpaDiag {
   bool attn_valu = false;            // MPA_ATTN_VALU: head dimension 16 on the VALU kernels instead of the MFMA ones
   // GEMM planner
   int gemm_variant = -1, gemm_splits = 0;   // MPA_GEMM_FORCE="variant,splits"
+  int gemm_panel_wgs = 0;            // MPA_GEMM_PANEL_WGS: workgroups the panel kernel aims for
+  bool gemm_no_panel = false;        // MPA_GEMM_NO_PANEL: short-K products on gemm_kernel instead of gemm_panel_kernel
   // kernel debug switches (honoured by -DMPA_DIAG builds only)
   int dbg_fwd = 0, dbg_wg15 = 0, dbg_head = 0, dbg_bfx = 0;   // MPA_DEBUG_FWD, MPA_DEBUG_WG15, MPA_HEAD_DEBUG, MPA_BFX_DEBUG
 };
@@ -80,6 +82,8 @@ inline MpaDiag mpa_diag_read() {
   g.attn_valu = set("MPA_ATTN_VALU");
   g.bfx_r = (int)num("MPA_BFX_R", 0);
   g.bfx_wg_s = (int)num("MPA_BFX_WG_S", 0);
+  g.gemm_no_panel = set("MPA_GEMM_NO_PANEL");
+  if (const char* e = getenv("MPA_GEMM_PANEL_WGS")) g.gemm_panel_wgs = atoi(e);
   if (const char* e = getenv("MPA_GEMM_FORCE")) {
     int v = -1, s = 0;
     if (sscanf(e, "%d,%d", &v, &s) == 2) { g.gemm_variant = v; g.gemm_splits = s; }

@@ -248,7 +248,11 @@ def test_upconcat(dev, g):
 
 
 @pytest.mark.parametrize("rows,K,N,act", [(104, 128, 8192, 1), (104, 8192, 128, 0), (50, 32, 64, 1), (7, 5, 3, 0),
-                                          (333, 1664, 3328, 0)])
+                                          (333, 1664, 3328, 0),
+                                          # short-K panel kernel (gemm_panel_kernel): K = 128 / 64 forward (B k-contiguous) and
+                                          # as the input gradient (B n-contiguous), ragged rows and column tiles
+                                          (300, 128, 8192, 1), (300, 8192, 128, 0), (261, 64, 1028, 1), (261, 1028, 64, 0),
+                                          (1000, 128, 1100, 0)])
 def test_linear(dev, rows, K, N, act):
     from multipitch_architectures_amd import ops
     x, w, b = _rand((rows, K), 1), _rand((N, K), 2, K ** -0.5), _rand((N,), 3, 0.1)
