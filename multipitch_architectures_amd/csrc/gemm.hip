@@ -293,6 +293,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pp) {
 // into registers behind the MFMAs of the previous tile; 4 b128 operand reads per 32 MFMAs; the epilogue goes through a
 // wave-private LDS patch as 16-byte stores, as in gemm_kernel.  BNC: B is n-contiguous (B[k][n], 4 x 4 register transposes
 // while staging) instead of k-contiguous (B[n][k]).
+// 71-77 -> 88-97 TFLOP/s.  What the remaining distance is made of was measured with three other arrangements of the same
+// tile (round 4, all within 3 % of this one on one box: 0.29-0.33 ms): the epilogue interleaved into the next tile's MFMA
+// stream from a second accumulator set; 8 waves in two groups that alternate between the MFMA phase and the epilogue /
+// staging phase across workgroup barriers; the same with the operands exchanged so that the accumulators hold C transposed
+// and go out as 16-byte stores without the LDS patch.  With the stores compiled out the kernel takes 0.24-0.26 ms, the stores
+// alone 0.11 ms (4 TB/s), together 0.29-0.32: whichever wave issues them, the stores (and the LDS patch writes) make little
+// progress beside a dense MFMA stream on the same SIMD, so their time adds to the MFMA time instead of hiding behind it.
 constexpr int PN = 64;                         // columns per tile
 constexpr int PBP = 132;                       // floats per B row in LDS (33 slots)
 
@@ -450,8 +457,9 @@ inline bool panel_ok(const GemmParams& p, int nbatch, int shared_c) {
 
 int launch_panel(const GemmParams& p, hipStream_t s) {
   const long mt = mpa_cdiv(p.M, 128), nt = mpa_cdiv(p.N, PN);
-  // ~3 workgroups per CU in flight, whole column tiles per workgroup
-  const long want = mpa_diag().gemm_panel_wgs > 0 ? mpa_diag().gemm_panel_wgs : 768;
+  // four column tiles per workgroup at batch 256 (13 workgroups per CU over the launch: short lives, the A panel loads of one
+  // hide behind the MFMAs of its neighbour on the CU), whole column tiles per workgroup
+  const long want = mpa_diag().gemm_panel_wgs > 0 ? mpa_diag().gemm_panel_wgs : 3328;
   long nsplit = std::max<long>(1, std::min<long>(nt, mpa_cdiv(want, mt)));
   const int cols = (int)(mpa_cdiv(nt, nsplit) * PN);
   nsplit = mpa_cdiv(p.N, cols);
