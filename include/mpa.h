@@ -344,6 +344,13 @@ int mpa_context_batch(const mpa_context_desc* d, int B, const uint64_t* src, con
                       const uint64_t* tgt, const int32_t* aug, const float* n1, const float* n2, const float* n3,
                       uint64_t seed, float* X, float* y, void* stream);
 
+/* 'aug:scalingfactor' of dataset_context_segm (libdl/data_loaders/hcqt_datasets.py:211-225): src = (harmonic 0, first frame
+ * of the window incl. context, bin 0) of an (n_harm, >= half_context + seglength + half_context, n_bins) window with
+ * chan_stride elements between harmonics; the seglength frames in the middle are resampled to new_len frames (linear,
+ * at linspace(0, seglength - 1, new_len)), the context halves copied.  out: (n_harm, new_len + 2 half_context, n_bins). */
+int mpa_time_scale(const float* src, int64_t chan_stride, int n_harm, int n_bins, int half_context, int seglength,
+                   int new_len, float* out, void* stream);
+
 /* ------------------------------------------------------------------ evaluation measures
  * replaces libdl/metrics/eval_metrics.py:8-116 (calculate_single_measure; the 11 measures of exp180d...py:150-151)
  * incl. libfmp/c5/c5s2_chord_rec_template.py:238-261 and libfmp/c3/c3s1_post_processing.py:60-68.

@@ -124,6 +124,7 @@ SIGNATURES = {
     "mpa_bce_fwd": (c_int, [_P, _P, _P, c_int64, _P]),
     "mpa_bce_bwd": (c_int, [_P, _P, _P, c_int64, _P, _P]),
     "mpa_ce_fwd_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, _P]),
+    "mpa_time_scale": (c_int, [_P, ctypes.c_int64, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "mpa_context_batch": (c_int, [ctypes.POINTER(ContextDesc), c_int, _P, _P, _P, _P, _P, _P, _P, ctypes.c_uint64, _P, _P, _P]),
     "mpa_eval_measures_workspace": (c_int64, [c_int64, c_int]),
     "mpa_eval_measures": (c_int, [_P, _P, c_int64, c_int, c_double, _P, _P, c_int64, _P]),

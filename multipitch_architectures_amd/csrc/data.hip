@@ -148,6 +148,40 @@ __global__ __launch_bounds__(256) void context_targets_kernel(CtxParams p) {
   }
 }
 
+
+// 'aug:scalingfactor' (hcqt_datasets.py:211-225): the `seglength` frames between the context halves resampled to `new_len`
+// frames by linear interpolation at linspace(0, seglength - 1, new_len) (scipy interp1d: slope and product in double, the
+// difference of the two samples in float), the context halves copied.  out: (n_harm, hc + new_len + hc, n_bins).
+__global__ __launch_bounds__(256) void time_scale_kernel(const float* __restrict__ src, long chan_stride, int n_harm, int n_bins,
+                                                         int hc, int seglength, int new_len, float* __restrict__ out) {
+  const int frames_out = new_len + 2 * hc;
+  const long n = (long)n_harm * frames_out * n_bins;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const int b = (int)(e % n_bins);
+    const int t = (int)((e / n_bins) % frames_out);
+    const int c = (int)(e / ((long)n_bins * frames_out));
+    const float* s = src + c * chan_stride + b;
+    float v;
+    if (t < hc) v = s[(long)t * n_bins];
+    else if (t >= hc + new_len) v = s[(long)(t - new_len + seglength) * n_bins];
+    else {
+      const int k = t - hc;
+      // numpy.linspace(0, L - 1, n): k * step with step = (L - 1) / (n - 1), the last point set to L - 1 exactly
+      const double x = new_len > 1 ? (k == new_len - 1 ? (double)(seglength - 1) : k * ((double)(seglength - 1) / (double)(new_len - 1)))
+                                   : 0.0;
+      int lo = (int)x;                                  // interp1d: lo = searchsorted(x) - 1 clipped to [0, L - 2]
+      if (x > 0.0 && (double)lo == x) lo -= 1;          // (side = 'left': an exact knot belongs to the interval below it)
+      lo = max(0, min(lo, seglength - 2));
+      if (seglength < 2) { v = s[(long)hc * n_bins]; }
+      else {
+        const float ylo = s[(long)(hc + lo) * n_bins], yhi = s[(long)(hc + lo + 1) * n_bins];
+        const double slope = (double)(yhi - ylo) / 1.0;
+        v = (float)(slope * (x - (double)lo) + (double)ylo);
+      }
+    }
+    out[e] = v;
+  }
+}
 }  // namespace
 
 extern "C" int mpa_context_batch(const mpa_context_desc* d, int B, const uint64_t* src, const int64_t* chan_stride,
@@ -174,5 +208,14 @@ extern "C" int mpa_context_batch(const mpa_context_desc* d, int B, const uint64_
   const long n = (long)B * d->seglength * d->n_out;
   MPA_LAUNCH(context_targets_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0,
              (hipStream_t)stream, p);
+  return mpa_launch_status();
+}
+
+extern "C" int mpa_time_scale(const float* src, int64_t chan_stride, int n_harm, int n_bins, int half_context, int seglength,
+                              int new_len, float* out, void* stream) {
+  if (!src || !out || n_harm < 1 || n_bins < 1 || half_context < 0 || seglength < 1 || new_len < 1) return MPA_ERR_ARG;
+  const long n = (long)n_harm * (new_len + 2L * half_context) * n_bins;
+  MPA_LAUNCH(time_scale_kernel, dim3((unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192)), dim3(256), 0,
+             (hipStream_t)stream, src, (long)chan_stride, n_harm, n_bins, half_context, seglength, new_len, out);
   return mpa_launch_status();
 }

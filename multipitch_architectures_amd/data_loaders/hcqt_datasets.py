@@ -9,8 +9,11 @@ Differences, all deliberate:
 * Random decisions (EQ parabola, tuning shift, transposition) are drawn on the host from a numpy PCG64 stream, noise by
   a counter-based generator in the kernel -- same distributions as the reference, not the same torch-CPU stream.  Pass
   ``draws=...`` to ``batch`` to dictate them (used by the parity tests).
-* ``'aug:scalingfactor'`` (time scaling, ``dataset_context_segm`` only) is not built: it resamples every patch to its own
-  random length, so its samples do not stack into a batch; requesting it raises.
+* ``'aug:scalingfactor'`` (time scaling, ``dataset_context_segm`` only, :211-225) resamples every patch to its own random
+  length, so its samples do not stack: they are served one per call (``ds[i]`` / ``batch([i])``; upstream a DataLoader can
+  only batch them with batch_size 1 as well), the input ``int(scalefac * seglength)`` frames plus context long beside
+  ``seglength`` target rows, as upstream.  ``dataset_context`` with the key raises upstream's assertion when an item is
+  requested (:77-78).
 Round 4: ``'aug:smooth_len'`` / ``'aug:smooth_win'`` (target smoothing at construction, :190-194) and the three plain-slicing
 classes ``dataset_context_segm_pitch`` (:292-330), ``dataset_context_segm_widetarget`` (:333-377) and
 ``dataset_context_measuresegm`` (:380-436) on the same launch.
@@ -70,9 +73,6 @@ class dataset_context:
         self.randomeq = params.get("aug:randomeq")
         self.noisestd = params.get("aug:noisestd")
         self.tuning = params.get("aug:tuning")
-        if self.scalingfactor:
-            raise NotImplementedError("'aug:scalingfactor' (time scaling) is not built: its patches have random lengths and "
-                                      "do not stack into a batch")
         if params.get("aug:smooth_len", 0) > 1:
             if not self._segm:
                 raise NotImplementedError("'aug:smooth_len' belongs to dataset_context_segm (hcqt_datasets.py:190-194)")
@@ -137,6 +137,8 @@ class dataset_context:
         return src.astype(np.uint64), cs, tgt.astype(np.uint64)
 
     def batch(self, indices, draws=None):
+        if self.scalingfactor:
+            raise AssertionError("Scaling not implemented for dataset_context!")      # hcqt_datasets.py:77-78
         return gather([(self, indices)], draws=draws)
 
     def __getitem__(self, index):
@@ -145,8 +147,57 @@ class dataset_context:
 
 
 class dataset_context_segm(dataset_context):
-    """``dataset_context_segm`` (hcqt_datasets.py:144-289) without time scaling: ``seglength`` target frames per patch."""
+    """``dataset_context_segm`` (hcqt_datasets.py:144-289): ``seglength`` target frames per patch.  With
+    ``'aug:scalingfactor'`` the frames between the context halves are first resampled to ``int(scalefac * seglength)`` frames,
+    ``scalefac = 1/f + 2 u (1 - 1/f)``, u uniform in [0, 1) (:212-213; ``draws["scale"]`` dictates it); one patch per call."""
     _segm = True
+
+    def batch(self, indices, draws=None):
+        if not self.scalingfactor:
+            return gather([(self, indices)], draws=draws)
+        idx = np.asarray(indices, dtype=np.int64).reshape(-1)
+        if idx.size != 1:
+            raise RuntimeError("'aug:scalingfactor' serves one patch per call: their lengths differ")
+        src, cs, _ = dataset_context.addresses(self, idx)          # bounds-checked window incl. context
+        if draws is not None and draws.get("scale") is not None:
+            scalefac = float(draws["scale"])
+        else:
+            scalefac = 1.0 / self.scalingfactor + 2.0 * float(self.rng.random()) * (1.0 - 1.0 / self.scalingfactor)
+        new_len = int(scalefac * self.seglength)
+        if new_len < 1:
+            raise RuntimeError(f"'aug:scalingfactor': scaled length {new_len} < 1")
+        hc = self.context // 2
+        frames = new_len + 2 * hc
+        scaled = torch.empty((self.inputs.shape[0], frames, self.inputs.shape[2]), dtype=torch.float32, device=self.device)
+        L.check(L.load().mpa_time_scale(ctypes.c_void_p(int(src[0])), ctypes.c_int64(int(cs[0])), self.inputs.shape[0],
+                                        self.inputs.shape[2], hc, self.seglength, new_len, _p(scaled),
+                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "mpa_time_scale")
+        # the remaining stages on the scaled window: same launch as every other patch, with its own frame count
+        keep = self.frames, self.desc
+        self.frames = frames
+        self.desc = L.ContextDesc(self.inputs.shape[0], self.inputs.shape[2], frames, self.targets.shape[1], self.seglength,
+                                  self.desc.flags, float(self.compression or 0.0), float(self.noisestd or 0.0))
+        self._scaled = (scaled, idx)
+        try:
+            X, y = gather([(self, idx)], draws=None if draws is None else {k: v for k, v in draws.items() if k != "scale"})
+        finally:
+            self.frames, self.desc = keep
+            self._scaled = None
+        X._mpa_keepalive = X._mpa_keepalive + (scaled,)
+        return X, y
+
+    _scaled = None
+
+    def addresses(self, indices):
+        src, cs, tgt = dataset_context.addresses(self, indices) if self._scaled is None else self._addresses_scaled()
+        return src, cs, tgt
+
+    def _addresses_scaled(self):
+        scaled, idx = self._scaled
+        start = idx * self.stride
+        tgt = self.targets.data_ptr() + (start + self.context // 2) * (self.targets.shape[1] * 4)
+        return (np.array([scaled.data_ptr()], dtype=np.uint64), np.array([scaled.shape[1] * scaled.shape[2]], dtype=np.int64),
+                tgt.astype(np.uint64))
 
 
 class dataset_context_segm_pitch(dataset_context_segm):

@@ -63,7 +63,12 @@ VARIANTS = [("xsegm_pitch", "dataset_context_segm_pitch", {"context": 75, "segle
              [5, 6, 8]),
             ("xmeasuresegm", "dataset_context_measuresegm", {"context": 75, "seglength": 2, "stride": 3, "compression": 10}, 72, 700, [0, 1, 3]),
             ("xsegm_smooth", "dataset_context_segm", {"context": 75, "seglength": 60, "stride": 45, "compression": 10,
-                                                      "aug:smooth_len": 6, "aug:smooth_win": "hann"}, 72, 400, [0, 2, 5])]
+                                                      "aug:smooth_len": 6, "aug:smooth_win": "hann"}, 72, 400, [0, 2, 5]),
+            # time scaling (:211-225): the one random decision is pinned by torch.manual_seed(900 + k) before item k and stored
+            ("xsegm_scale", "dataset_context_segm", {"context": 75, "seglength": 60, "stride": 45, "compression": 10,
+                                                     "aug:scalingfactor": 1.5}, 72, 400, [0, 1, 2, 4, 5]),
+            ("xsegm_scale2", "dataset_context_segm", {"context": 25, "seglength": 100, "stride": 20, "compression": None,
+                                                      "aug:scalingfactor": 2}, 72, 400, [0, 3, 9])]
 
 
 def variants():
@@ -78,6 +83,13 @@ def variants():
         out = {"params": np.array(json.dumps(params)), "cls": np.array(cls_name), "n_out": np.array(n_out), "frames": np.array(frames),
                "indices": np.array(indices, dtype=np.int64), "len": np.array(len(ds)), "measures": np.array(MEASURES, dtype=np.int64)}
         for k, index in enumerate(indices):
+            if "aug:scalingfactor" in params:            # the value the class is about to draw (:212-213), same arithmetic
+                torch.manual_seed(900 + k)
+                sf = params["aug:scalingfactor"]
+                scalefac = 1 / sf + 2 * torch.rand(1) * (1 - 1 / sf)
+                out[f"{k}.scale"] = np.array(float(scalefac))
+                out[f"{k}.new_len"] = np.array(int(scalefac * params["seglength"]))
+                torch.manual_seed(900 + k)
             X, y = ds[index]
             X = np.asarray(X, dtype=np.float32)
             out[f"{k}.shape"] = np.array(X.shape)

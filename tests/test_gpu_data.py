@@ -113,8 +113,9 @@ def test_context_rejects_bad_requests():
     ds = dataset_context(inputs, targets, {"context": 75, "stride": 10, "compression": 10})
     with pytest.raises(IndexError):
         ds.batch([len(ds) + 3])
-    with pytest.raises(NotImplementedError):
-        dataset_context(inputs, targets, {"context": 75, "stride": 10, "compression": 10, "aug:scalingfactor": 1.2})
+    scaled = dataset_context(inputs, targets, {"context": 75, "stride": 10, "compression": 10, "aug:scalingfactor": 1.2})
+    with pytest.raises(AssertionError, match="Scaling not implemented for dataset_context"):      # upstream's own (:77-78)
+        scaled[0]
     X, y = ds[0]
     assert tuple(X.shape) == (6, 75, 216) and tuple(y.shape) == (1, 1, 72)
 
@@ -134,8 +135,14 @@ def test_slicing_dataset_variants(path):
     args = (inputs, targets) + ((g["measures"],) if cls_name == "dataset_context_measuresegm" else ())
     ds = getattr(DL, cls_name)(*args, dict(params))
     assert len(ds) == int(g["len"])
+    scaling = "aug:scalingfactor" in params       # time scaling (:211-225): the drawn factor is stored with the item
     for k, index in enumerate(g["indices"]):
-        X, y = ds[int(index)]
+        if scaling:
+            Xb, yb = ds.batch([int(index)], draws={"aug": np.zeros((1, 4), np.int32), "scale": float(g[f"{k}.scale"])})
+            X, y = Xb[0], yb[0]
+            assert X.shape[1] == int(g[f"{k}.new_len"]) + 2 * (params["context"] // 2)
+        else:
+            X, y = ds[int(index)]
         X, y = X.cpu().numpy(), y.cpu().numpy()
         assert list(X.shape) == list(g[f"{k}.shape"]) and y.shape == g[f"{k}.y"].shape
         np.testing.assert_allclose(X.ravel()[::11], g[f"{k}.xs"], rtol=5e-7, atol=2e-9)
@@ -145,7 +152,13 @@ def test_slicing_dataset_variants(path):
             np.testing.assert_allclose(y, g[f"{k}.y"], rtol=1e-6, atol=1e-7)
         else:
             np.testing.assert_array_equal(y, g[f"{k}.y"])
-    if cls_name != "dataset_context_measuresegm":           # batches of equal-length segments stack
+    if scaling:                                             # own random factor per item: lengths within the stated range, one per call
+        lo, hi = params["seglength"] / params["aug:scalingfactor"], params["seglength"] * (2 - 1 / params["aug:scalingfactor"])
+        lens = {ds[0][0].shape[1] - 2 * (params["context"] // 2) for _ in range(12)}
+        assert len(lens) > 1 and all(int(lo) <= n <= int(hi) for n in lens)
+        with pytest.raises(RuntimeError):
+            ds.batch([0, 1])
+    elif cls_name != "dataset_context_measuresegm":         # batches of equal-length segments stack
         Xb, yb = ds.batch([int(i) for i in g["indices"]])
         assert Xb.shape[0] == len(g["indices"]) and torch.equal(Xb[1], ds[int(g["indices"][1])][0])
     else:
