@@ -89,6 +89,7 @@ FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
           const int tx = txi < 6 ? tx0 + txi : tx0 << (txi - 4);
           if (tx > OW) break;
           const int TW = (int)mpa_cdiv(OW, tx);
+          if ((diag.fwd_th && TH != diag.fwd_th) || (diag.fwd_tw && TW != diag.fwd_tw)) continue;   // diagnostics
           const int ty = (int)mpa_cdiv(OH, TH);
           const int IH = (TH - 1) * sh + kh, IW = (TW - 1) * sw + kw;
           for (int lwi = 0; lwi < 2; ++lwi) {
@@ -128,7 +129,8 @@ FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
             // their address arithmetic per NB*PB MFMAs (about half of that in the tap-vector kernels); barrier term:
             // ~400 cycles per (chunk, filter row) against kw*(CK/4)*NB*PB MFMAs of 32 cycles
             const double opnd = (KWS ? 0.13 : 0.25) * (NB + PB) / (double)(NB * PB);
-            const double per_block = (double)P * NB * (1.0 + 0.05 * IH * IW / P + opnd) * (1.0 + 0.02 * lwi) *
+            const double halo_w = (NB == 1 && diag.fwd_halo_nb1 >= 0.0) ? diag.fwd_halo_nb1 : 0.05;
+            const double per_block = (double)P * NB * (1.0 + halo_w * IH * IW / P + opnd) * (1.0 + 0.02 * lwi) *
                                      (1.0 + 12.5 / ((double)kw * (CK / 4) * NB * PB)) * (quad ? 1.0 : 1.08);
             // large grids: throughput (blocks * per_block / 256 CUs); small grids: whole rounds
             const double fill = (double)(TH * TW) / P;      // lanes doing useful work

@@ -21,6 +21,8 @@
 struct MpaDiag {
   // forward / backward-data planner (plan_fwd)
   int fwd_nb = 0, fwd_pb = 0;        // MPA_FWD_FORCE="NB,PB": restrict the tile search
+  int fwd_th = 0, fwd_tw = 0;        // MPA_FWD_TILE="TH,TW": one pixel-tile shape (0 = any)
+  double fwd_halo_nb1 = -1.0;        // MPA_FWD_HALO_NB1: halo weight of the cost model for 16-cout tiles (-1: the planner's own)
   int fwd_ks_max = 16;               // MPA_FWD_KS_MAX
   int fwd_ks_force = 0;              // MPA_FWD_KS_FORCE
   bool fold_off = false;             // MPA_FOLD_OFF: no cout-remainder fold for the 15x15 layers
@@ -60,6 +62,8 @@ inline MpaDiag mpa_diag_read() {
   auto num = [](const char* name, long dflt) { const char* e = getenv(name); return e ? atol(e) : dflt; };
   auto set = [](const char* name) { return getenv(name) != nullptr; };
   if (const char* e = getenv("MPA_FWD_FORCE")) sscanf(e, "%d,%d", &g.fwd_nb, &g.fwd_pb);
+  if (const char* e = getenv("MPA_FWD_TILE")) sscanf(e, "%d,%d", &g.fwd_th, &g.fwd_tw);
+  if (const char* e = getenv("MPA_FWD_HALO_NB1")) g.fwd_halo_nb1 = atof(e);
   g.fwd_ks_max = (int)num("MPA_FWD_KS_MAX", 16);
   g.fwd_ks_force = (int)num("MPA_FWD_KS_FORCE", 0);
   g.fold_off = set("MPA_FOLD_OFF");
