@@ -29,6 +29,7 @@ struct FwdPlan {
   bool ok;
   int KWS, KWP;   // tap-vector filter layout (kw 15 / 9, PB >= 4): kernel specialised on kw, slab rows of KWP taps
   int KS;         // input-channel split: blockIdx.z owns nChunks/KS chunks and adds its partial sums atomically
+  double cost = 0.0;   // the cost model's value for this plan (describe_plan)
 };
 
 // Which problems use the tap-vector layout [ck][cout][dx padded to KWP]: the A operand of 4 consecutive taps is then one
@@ -166,6 +167,7 @@ FwdPlan plan_fwd(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
               bestcost = cost;
               best = FwdPlan{NB, PB, TH, TW, ty, tx, CK, nChunks, IH, IW, LW, CHP, COT, cotp, coTiles, OH, OW,
                              quad, lds, true, KWS, KWP, KS};
+              best.cost = cost;
             }
           }
         }
