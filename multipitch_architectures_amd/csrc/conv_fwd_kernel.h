@@ -18,8 +18,11 @@ namespace {
 // ------------------------------------------------------------------------------------------------ forward kernel
 // PH (phase stores): backward-data variants whose couts are (channel, x/y phase) pairs -- a separate instantiation, as
 // EF is: the 16->128 forward sits on a register cliff and lost 10 % whenever either was compiled into the common kernel
-template <int NB, int PB, int KW = 0, bool EF = false, bool PH = false>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
+// MINW = 2: built to at most 256 registers (two waves per SIMD) -- only for <2,12,9>, whose natural allocation (256 VGPRs + 23
+// AGPRs) leaves one workgroup per CU: with 26 spilled registers and two resident workgroups the 64 -> 32 9x9 forward at batch 256
+// runs at 115 instead of 104 TFLOP/s; small grids (local batch 32) keep the unspilled build, which is faster there.
+template <int NB, int PB, int KW = 0, bool EF = false, bool PH = false, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void conv_fwd_kernel(const ConvFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lds_in = lds;
   float* lds_w0 = lds + p.IN64;          // two filter-slab buffers: slab dy+1 streams in while dy is consumed
@@ -351,15 +354,15 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdParams p) {
   }
 }
 
-template <int NB, int PB, int KW, bool EF, bool PH = false>
+template <int NB, int PB, int KW, bool EF, bool PH = false, int MINW = 1>
 int launch_fwd_ef(const FwdPlan& pl, const ConvFwdParams& p, dim3 grid, hipStream_t s) {
   static bool big_lds = false;
   if (!big_lds) {
-    (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<NB, PB, KW, EF, PH>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<NB, PB, KW, EF, PH, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               80 * 1024);
     big_lds = true;
   }
-  MPA_LAUNCH((conv_fwd_kernel<NB, PB, KW, EF, PH>), grid, dim3(256), pl.lds_bytes, s, p);
+  MPA_LAUNCH((conv_fwd_kernel<NB, PB, KW, EF, PH, MINW>), grid, dim3(256), pl.lds_bytes, s, p);
   return mpa_launch_status();
 }
 
@@ -373,6 +376,10 @@ int launch_fwd_one(const FwdPlan& pl, const ConvFwdParams& p, dim3 grid, hipStre
   }
   if constexpr (KW < 9) {
     if (p.quad && (p.W & 3)) return launch_fwd_ef<NB, PB, KW, true>(pl, p, grid, s);
+  }
+  if constexpr (NB == 2 && PB == 12 && KW == 9) {      // two resident workgroups once the grid has work for them (MINW above)
+    if ((long)grid.x * grid.z >= 1024 && 2 * pl.lds_bytes <= 160 * 1024 && !mpa_diag().fwd_no_minw)
+      return launch_fwd_ef<NB, PB, KW, false, false, 2>(pl, p, grid, s);
   }
   return launch_fwd_ef<NB, PB, KW, false>(pl, p, grid, s);
 }

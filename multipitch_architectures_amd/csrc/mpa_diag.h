@@ -22,6 +22,7 @@ struct MpaDiag {
   // forward / backward-data planner (plan_fwd)
   int fwd_nb = 0, fwd_pb = 0;        // MPA_FWD_FORCE="NB,PB": restrict the tile search
   int fwd_th = 0, fwd_tw = 0;        // MPA_FWD_TILE="TH,TW": one pixel-tile shape (0 = any)
+  bool fwd_no_minw = false;          // MPA_FWD_NO_MINW: <2,12,9> always as the one-workgroup-per-CU build
   double fwd_halo_nb1 = -1.0;        // MPA_FWD_HALO_NB1: halo weight of the cost model for 16-cout tiles (-1: the planner's own)
   int fwd_ks_max = 16;               // MPA_FWD_KS_MAX
   int fwd_ks_force = 0;              // MPA_FWD_KS_FORCE
@@ -64,6 +65,7 @@ inline MpaDiag mpa_diag_read() {
   if (const char* e = getenv("MPA_FWD_FORCE")) sscanf(e, "%d,%d", &g.fwd_nb, &g.fwd_pb);
   if (const char* e = getenv("MPA_FWD_TILE")) sscanf(e, "%d,%d", &g.fwd_th, &g.fwd_tw);
   if (const char* e = getenv("MPA_FWD_HALO_NB1")) g.fwd_halo_nb1 = atof(e);
+  g.fwd_no_minw = set("MPA_FWD_NO_MINW");
   g.fwd_ks_max = (int)num("MPA_FWD_KS_MAX", 16);
   g.fwd_ks_force = (int)num("MPA_FWD_KS_FORCE", 0);
   g.fold_off = set("MPA_FOLD_OFF");
