@@ -258,6 +258,13 @@ int mpa_add_rows_bcast(const float* x, const float* pe, float* y, int B, int64_t
  * C[M,N] (+)= A[M,K] * op(B) (+ bias[N]) with act; A(m,k)=A[m*lda_m+k*lda_k], B(k,n)=Bm[k*ldb_k+n*ldb_n]. */
 int mpa_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float* Bm, int64_t ldb_k, int64_t ldb_n,
              const float* bias, float* C, int64_t ldc, int M, int N, int K, int accumulate, int act, void* stream);
+/* C[M,N] = (A B) where mask > 0, else 0: the input gradient of a Linear layer whose input is a ReLU output (mask, laid out like the
+ * contiguous C) with that ReLU's backward pass folded in -- dh = (dy W2) * (h > 0) of the transformer MLP, libdl/nn_models/
+ * unet_cnns.py:137-141,176.  Strides as mpa_gemm.  Fused in the short-K panel kernel for K = 128 with B n-contiguous; any other
+ * shape runs mpa_gemm followed by mpa_act_bwd in place (same values). */
+int mpa_gemm_masked(const float* A, int64_t lda_m, int64_t lda_k, const float* B, int64_t ldb_k, int64_t ldb_n,
+                    const float* mask, float* C, int M, int N, int K, void* stream);
+
 /* nbatch <= 4 products of identical shape and strides in one launch (the q/k/v projections of transformer_enc_layer and
  * the three in-projections of nn.MultiheadAttention, unet_cnns.py:131-135,153): problem b uses A[b], B[b], bias[b], C[b]
  * (host arrays of device pointers, read at launch).  shared_c != 0: every C[b] is the same matrix and receives the SUM of

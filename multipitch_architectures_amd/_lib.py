@@ -113,6 +113,7 @@ SIGNATURES = {
     "mpa_channel_sum": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "mpa_add_rows_bcast": (c_int, [_P, _P, _P, c_int, c_int64, _P]),
     "mpa_gemm": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P]),
+    "mpa_gemm_masked": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, _P, c_int, c_int, c_int, _P]),
     "mpa_gemm_batched": (c_int, [c_int, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P]),
     "mpa_gemm_bf16x3_supported": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int, c_int, c_int]),
     "mpa_gemm_bf16x3": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P]),

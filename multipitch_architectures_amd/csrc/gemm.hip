@@ -28,6 +28,7 @@ struct GemmParams {
   const float* Bb[4];
   const float* biasb[4];
   float* Cb[4];
+  const float* mask;   // mpa_gemm_masked: C = (A B) where mask > 0, else 0 (mask laid out like C: the ReLU output whose gradient C is)
 };
 
 // Operand tile staging, split in two halves so that the global loads of k-tile t+1 are in flight while the MFMAs of
@@ -346,7 +347,10 @@ __device__ __forceinline__ void panel_store_b(const f32x4 (&rb)[PN * 16 * G / 4 
   }
 }
 
-template <int G, bool BNC>
+// MASK: the product is the gradient of a ReLU output laid out like C (p.mask): elements whose mask value is not positive are
+// stored as zero (mpa_gemm_masked -- the activation's backward pass folded into the GEMM that produces its input).  The tile's mask
+// quads are fetched with the B prefetch, in the layout of the stores.
+template <int G, bool BNC, bool MASK = false>
 __global__ __launch_bounds__(256) void gemm_panel_kernel(const GemmParams p, int cols_per_wg) {
   constexpr int K = 16 * G;
   __shared__ __attribute__((aligned(16))) float Bs[PN * PBP];
@@ -378,6 +382,12 @@ __global__ __launch_bounds__(256) void gemm_panel_kernel(const GemmParams p, int
   constexpr int PW = PN + 4;
   const bool has_bias = p.bias != nullptr, relu = p.act == MPA_ACT_RELU;
   panel_store_b<G, BNC>(rb, Bs, tid, bn4, bkk);
+  // The A panel is complete before the loop: left pending, the compiler re-issues its first-use waits inside every tile's MFMA
+  // stream (it cannot tell the first pass from the later ones), where they then wait for that tile's prefetches.
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int sg = 0; sg < G; ++sg) asm volatile("" : "+v"(a[i][sg]));
   __syncthreads();
   for (int n0 = nbeg; n0 < nend; n0 += PN) {
     // next tile's loads fly behind this tile's MFMAs (the last pass re-reads the last columns); the bias of the epilogue too
@@ -388,6 +398,16 @@ __global__ __launch_bounds__(256) void gemm_panel_kernel(const GemmParams p, int
     if (has_bias) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) bj[j] = p.bias[min(n0 + j * 16 + l16, p.N - 1)];
+    }
+    f32x4 mk[MASK ? 2 : 1][MASK ? 4 : 1];               // mask quads of the lane's eight stores (clamped addresses)
+    if constexpr (MASK) {
+      const float* mbase = p.mask + min(n0 + (lane & 15) * 4, p.N - 4);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          mk[i][q] = *reinterpret_cast<const f32x4*>(mbase + (long)min(m0 + i * 16 + q * 4 + (lane >> 4), p.M - 1) * p.ldc);
+      __builtin_amdgcn_sched_barrier(0);               // (issued in front of the MFMAs, not behind them)
     }
     f32x4 acc[2][4];
 #pragma unroll
@@ -414,6 +434,14 @@ __global__ __launch_bounds__(256) void gemm_panel_kernel(const GemmParams p, int
     __builtin_amdgcn_sched_barrier(0);                 // (keeps the staging's register moves, and their wait, below the MFMAs)
     __syncthreads();                                   // every wave is done with this B tile
     panel_store_b<G, BNC>(rb, Bs, tid, bn4, bkk);
+    if constexpr (MASK) {
+      // the mask quads are complete here, before the first store: a wait for them inside the conditional store blocks would
+      // count no store as certainly issued and wait for all of them (vmcnt(0))
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(mk[i][q]));
+    }
     // epilogue: each 16-row slab of the wave tile through the wave's LDS patch, then 16 lanes x float4 per row
     constexpr int C4 = PN / 4;                         // 16 float4 per row: 4 rows per store instruction
     const int c4 = lane % C4, rr = lane / C4;
@@ -433,7 +461,11 @@ __global__ __launch_bounds__(256) void gemm_panel_kernel(const GemmParams p, int
       for (int q = 0; q < 4; ++q) {
         const int row = q * 4 + rr;
         const int m = m0 + i * 16 + row;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(patch + row * PW + c4 * 4);
+        f32x4 v = *reinterpret_cast<const f32x4*>(patch + row * PW + c4 * 4);
+        if constexpr (MASK) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = mk[i][q][c] > 0.f ? v[c] : 0.f;
+        }
         float* dst = p.C + (long)m * p.ldc + n;
         if (interior) *reinterpret_cast<f32x4*>(dst) = v;               // wave-uniform: no divergence on the common path
         else if (m < p.M && n + 3 < p.N) *reinterpret_cast<f32x4*>(dst) = v;
@@ -465,6 +497,10 @@ int launch_panel(const GemmParams& p, hipStream_t s) {
   nsplit = mpa_cdiv(p.N, cols);
   const dim3 grid((unsigned)nsplit, (unsigned)mt);
   const bool bnc = p.ldb_n == 1 && p.ldb_k != 1;
+  if (p.mask) {                 // built for the one shape that uses it: K = 128, B n-contiguous (panel_ok_masked)
+    MPA_LAUNCH((gemm_panel_kernel<8, true, true>), grid, dim3(256), 0, s, p, cols);
+    return mpa_launch_status();
+  }
   if (p.K == 128) {
     if (bnc) MPA_LAUNCH((gemm_panel_kernel<8, true>), grid, dim3(256), 0, s, p, cols);
     else MPA_LAUNCH((gemm_panel_kernel<8, false>), grid, dim3(256), 0, s, p, cols);
@@ -690,6 +726,20 @@ extern "C" int mpa_gemm(const float* A, int64_t lda_m, int64_t lda_k, const floa
   if (!A || !Bm || !C || M <= 0 || N <= 0 || K <= 0) return MPA_ERR_ARG;
   GemmParams p{A, Bm, bias, C, (long)lda_m, (long)lda_k, (long)ldb_k, (long)ldb_n, (long)ldc, M, N, K, accumulate, act, K};
   return gemm_impl(p, 1, 0, (hipStream_t)stream);
+}
+
+extern "C" int mpa_gemm_masked(const float* A, int64_t lda_m, int64_t lda_k, const float* Bm, int64_t ldb_k, int64_t ldb_n,
+                               const float* mask, float* C, int M, int N, int K, void* stream) {
+  if (!A || !Bm || !mask || !C || M <= 0 || N <= 0 || K <= 0) return MPA_ERR_ARG;
+  GemmParams p{A, Bm, nullptr, C, (long)lda_m, (long)lda_k, (long)ldb_k, (long)ldb_n, (long)N, M, N, K, 0, MPA_ACT_NONE, K};
+  // the panel kernel's masked build serves K = 128 with B n-contiguous (the input gradient of Linear(8192, 128) behind a ReLU:
+  // unet_cnns.py:137-141); anything else is the plain product followed by the ReLU backward pass in place
+  const bool fused = p.K == 128 && p.ldb_n == 1 && p.ldb_k != 1 && (reinterpret_cast<uintptr_t>(mask) & 15) == 0 &&
+                     panel_ok(p, 1, 0) && !mpa_diag().gemm_no_mask_fuse;
+  if (fused) { p.mask = mask; return launch_panel(p, (hipStream_t)stream); }
+  const int rc = gemm_impl(p, 1, 0, (hipStream_t)stream);
+  if (rc != MPA_OK) return rc;
+  return mpa_act_bwd(C, mask, C, (long)M * N, MPA_ACT_RELU, 0.f, stream);
 }
 
 extern "C" int mpa_gemm_batched(int nbatch, const float* const* A, int64_t lda_m, int64_t lda_k, const float* const* Bm,

@@ -53,6 +53,7 @@ struct MpaDiag {
   // GEMM planner
   int gemm_variant = -1, gemm_splits = 0;   // MPA_GEMM_FORCE="variant,splits"
   int gemm_panel_wgs = 0;            // MPA_GEMM_PANEL_WGS: workgroups the panel kernel aims for
+  bool gemm_no_mask_fuse = false;    // MPA_GEMM_NO_MASK_FUSE: mpa_gemm_masked as product + masking pass for every shape
   bool gemm_no_panel = false;        // MPA_GEMM_NO_PANEL: short-K products on gemm_kernel instead of gemm_panel_kernel
   // kernel debug switches (honoured by -DMPA_DIAG builds only)
   int dbg_fwd = 0, dbg_wg15 = 0, dbg_head = 0, dbg_bfx = 0;   // MPA_DEBUG_FWD, MPA_DEBUG_WG15, MPA_HEAD_DEBUG, MPA_BFX_DEBUG
@@ -89,6 +90,7 @@ inline MpaDiag mpa_diag_read() {
   g.bfx_r = (int)num("MPA_BFX_R", 0);
   g.bfx_wg_s = (int)num("MPA_BFX_WG_S", 0);
   g.gemm_no_panel = set("MPA_GEMM_NO_PANEL");
+  g.gemm_no_mask_fuse = set("MPA_GEMM_NO_MASK_FUSE");
   if (const char* e = getenv("MPA_GEMM_PANEL_WGS")) g.gemm_panel_wgs = atoi(e);
   if (const char* e = getenv("MPA_GEMM_FORCE")) {
     int v = -1, s = 0;

@@ -1186,6 +1186,66 @@ def linear(x, weight, bias=None, act=ACT_NONE):
     return LinearFn.apply(x, weight, bias, act)
 
 
+class MlpReluFn(torch.autograd.Function):
+    """y = relu(x W0^T + b0) W1^T + b1 -- the transformer layer's `mlp` (unet_cnns.py:137-141,176) as one autograd node, so that
+    the ReLU's backward pass is folded into the GEMM that produces its input: dh = (dy W1) * (h > 0) is one launch
+    (`mpa_gemm_masked`) instead of a product and a masking pass over the (rows, mlp_dim) tensor.  Same kernels and the same values
+    as linear(linear(x, W0, b0, ACT_RELU), W1, b1) otherwise."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1):
+        x, w0, b0, w1, b1 = _c(x), _c(w0), _c(b0), _c(w1), _c(b1)
+        H, K = w0.shape
+        N = w1.shape[0]
+        if x.shape[-1] != K or w1.shape[1] != H:
+            raise RuntimeError(f"mlp_relu: shapes {tuple(x.shape)}, {tuple(w0.shape)}, {tuple(w1.shape)} do not chain")
+        rows = x.numel() // K
+        h = torch.empty(x.shape[:-1] + (H,), dtype=torch.float32, device=x.device)
+        _gemm(_p(x), K, 1, _p(w0), 1, K, _p(b0), _p(h), H, rows, H, K, 0, ACT_RELU)
+        y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+        _gemm(_p(h), H, 1, _p(w1), 1, H, _p(b1), _p(y), N, rows, N, H)
+        ctx.has_b0, ctx.has_b1 = b0 is not None, b1 is not None
+        ctx.save_for_backward(x, w0, w1, h)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w0, w1, h = ctx.saved_tensors
+        dy = _c(dy)
+        H, K = w0.shape
+        N = w1.shape[0]
+        rows = x.numel() // K
+        lib = _lib()
+        dx = dw0 = db0 = dw1 = db1 = None
+        if ctx.needs_input_grad[3]:
+            dw1 = torch.empty_like(w1)
+            _gemm(_p(dy), 1, N, _p(h), H, 1, None, _p(dw1), H, N, H, rows)
+        if ctx.has_b1 and ctx.needs_input_grad[4]:
+            db1 = torch.empty(N, dtype=torch.float32, device=x.device)
+            _chk(lib.mpa_colsum(_p(dy), _p(db1), rows, N, 0, _s()), "mpa_colsum")
+        if any(ctx.needs_input_grad[:3]):
+            dh = torch.empty_like(h)
+            if _Precision.conv == "bf16x3" or _Probe.match is not None:      # the mode's own GEMMs / the probe's launch keys
+                _gemm(_p(dy), N, 1, _p(w1), H, 1, None, _p(dh), H, rows, H, N)
+                _chk(lib.mpa_act_bwd(_p(dh), _p(h), _p(dh), dh.numel(), ACT_RELU, 0.0, _s()), "mpa_act_bwd")
+            else:
+                _chk(lib.mpa_gemm_masked(_p(dy), N, 1, _p(w1), H, 1, _p(h), _p(dh), rows, H, N, _s()), "mpa_gemm_masked")
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                _gemm(_p(dh), H, 1, _p(w0), K, 1, None, _p(dx), K, rows, K, H)
+            if ctx.needs_input_grad[1]:
+                dw0 = torch.empty_like(w0)
+                _gemm(_p(dh), 1, H, _p(x), K, 1, None, _p(dw0), K, H, K, rows)
+            if ctx.has_b0 and ctx.needs_input_grad[2]:
+                db0 = torch.empty(H, dtype=torch.float32, device=x.device)
+                _chk(lib.mpa_colsum(_p(dh), _p(db0), rows, H, 0, _s()), "mpa_colsum")
+        return dx, dw0, db0, dw1, db1
+
+
+def mlp_relu(x, w0, b0, w1, b1):
+    return MlpReluFn.apply(x, w0, b0, w1, b1)
+
+
 class QKVLinearFn(torch.autograd.Function):
     """q_linear / k_linear / v_linear of transformer_enc_layer (bias-free, unet_cnns.py:131-133,153) applied to the same
     tensor: three products in one launch, and in backward one launch each for the three weight gradients and for the

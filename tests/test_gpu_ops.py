@@ -270,6 +270,33 @@ def test_linear(dev, rows, K, N, act):
     _close(bg.grad, br.grad, 3e-5)
 
 
+@pytest.mark.parametrize("rows,K,H", [(300, 128, 8192), (1000, 128, 1100), (50, 32, 64), (261, 64, 1028), (7, 128, 2048)])
+def test_mlp_relu_is_the_two_linears(dev, rows, K, H):
+    """ops.mlp_relu (transformer mlp, unet_cnns.py:137-141,176: one autograd node, the ReLU's backward pass folded into the GEMM
+    that produces its input -- mpa_gemm_masked, fused in the panel kernel for K = 128, product + masking pass otherwise) against
+    linear(linear(x, W0, b0, relu), W1, b1): the same kernels compute the same values (up to the order of the atomically added K
+    splits of the long products, which is not fixed from launch to launch), and both against float64."""
+    from multipitch_architectures_amd import ops
+    x, w0, b0 = _rand((rows, K), 1), _rand((H, K), 2, K ** -0.5), _rand((H,), 3, 0.1)
+    w1, b1, gy = _rand((K, H), 4, H ** -0.5), _rand((K,), 5, 0.1), _rand((rows, K), 6)
+    ref = [t.to(dev).requires_grad_(True) for t in (x, w0, b0, w1, b1)]
+    got = [t.to(dev).requires_grad_(True) for t in (x, w0, b0, w1, b1)]
+    yr = ops.linear(ops.linear(ref[0], ref[1], ref[2], ops.ACT_RELU), ref[3], ref[4])
+    yr.backward(gy.to(dev))
+    y = ops.mlp_relu(*got)
+    y.backward(gy.to(dev))
+    _close(y, yr, 2e-6)
+    for a, b, name in zip(got, ref, ("x", "w0", "b0", "w1", "b1")):
+        _close(a.grad, b.grad, 2e-6)
+    # and against float64
+    x64 = [t.double().requires_grad_(True) for t in (x, w0, b0, w1, b1)]
+    y64 = F.linear(torch.relu(F.linear(x64[0], x64[1], x64[2])), x64[3], x64[4])
+    y64.backward(gy.double())
+    _close(y, y64, 3e-5)
+    for a, b in zip(got, x64):
+        _close(a.grad, b.grad, 1e-4)
+
+
 @pytest.mark.parametrize("B,S,E,h", [(8, 52, 128, 8), (25, 52, 128, 8), (50, 13, 32, 4), (1, 5, 32, 8), (300, 7, 64, 8),
                                      (256, 4, 256, 8),
                                      # head dimension 16 = the MFMA kernels (attn16_*): ragged query / key tiles, several
