@@ -227,12 +227,17 @@ int mpa_dropout(const float* x, float* y, int64_t n, float p, const uint64_t* rn
  * basic_cnns.py:414-418) and of every model's head stage conv2 (kh = 13, basic_cnns.py:380-385, unet_cnns.py:538-543).
  * h, out, residual: [planes][H][W] fp32; residual may be NULL; p == 0 (evaluation) skips the mask and needs no rng_state.
  * The mask is mpa_dropout's for the same (rng_state, offset).  which ([planes][H][W] int8, may be NULL when no gradient
- * is needed) records the window row 0..kh-1 of each maximum for mpa_poolrows_dropout_bwd, which returns d/dh
+ * is needed) records the window row 0..kh-1 of each maximum (bits 0-3) and whether it is positive (bit 6 set: not) for mpa_poolrows_dropout_bwd, which returns d/dh
  * (d/dresidual is dout).  Other kh: MPA_ERR_UNSUPPORTED. */
 int mpa_poolrows_dropout_add_fwd(const float* h, const float* residual, float* out, int8_t* which, int64_t planes, int H,
                                  int W, int kh, float p, const uint64_t* rng_state, uint64_t offset, void* stream);
 int mpa_poolrows_dropout_bwd(const float* dout, const int8_t* which, float* dh, int64_t planes, int H, int W, int kh, float p,
                              const uint64_t* rng_state, uint64_t offset, void* stream);
+/* the same with the backward pass of the ReLU / LeakyReLU folded in that the convolution producing h applied in its epilogue
+ * (nn.Sequential(Conv2d, LeakyReLU, MaxPool2d, Dropout): basic_cnns.py:371-385, unet_cnns.py:538-543): d/d(pre-activation) =
+ * (d/dh) * (h > 0 ? 1 : neg_slope), the sign taken from the flag mpa_poolrows_dropout_add_fwd leaves in `which`. */
+int mpa_poolrows_dropout_act_bwd(const float* dout, const int8_t* which, float* dh, int64_t planes, int H, int W, int kh, float p,
+                                 const uint64_t* rng_state, uint64_t offset, float neg_slope, void* stream);
 /* table[i] = host_ptrs[i], i < n: device pointer table written by kernels whose arguments carry the pointers (no
  * memcpy, nothing for the host to keep alive; capturable in a HIP graph)                                       */
 int mpa_store_ptrs(const void** table, const void* const* host_ptrs, int n, void* stream);

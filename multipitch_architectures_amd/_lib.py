@@ -102,6 +102,7 @@ SIGNATURES = {
     "mpa_dropout": (c_int, [_P, _P, c_int64, c_float, _P, c_uint64, _P]),
     "mpa_poolrows_dropout_add_fwd": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_float, _P, c_uint64, _P]),
     "mpa_poolrows_dropout_bwd": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int, c_float, _P, c_uint64, _P]),
+    "mpa_poolrows_dropout_act_bwd": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int, c_float, _P, c_uint64, c_float, _P]),
     "mpa_u64_add": (c_int, [_P, c_uint64, _P]),
     "mpa_gather_copy": (c_int, [_P, _P, _P, _P, c_int, _P]),
     "mpa_store_ptrs": (c_int, [_P, _P, c_int, _P]),

@@ -85,7 +85,9 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
 // each way (0.94 GB).  A thread owns V adjacent columns and R consecutive rows: it loads the R + KH - 1 input rows once
 // and forms the R windows in registers.  Same rules as the separate kernels, bit for bit: first maximum wins and a NaN
 // propagates (maxpool_fwd_plane_kernel), the keep mask is rng_uniform(seed, base + offset + flat index) >= p
-// (dropout_kernel), and the sum is (pooled * scale) + residual.  `which` records the window row (0..KH-1) of the maximum.
+// (dropout_kernel), and the sum is (pooled * scale) + residual.  `which` records the window row (0..KH-1) of the maximum and whether it is positive.
+constexpr int POOLROWS_NONPOS = 0x40;     // flag in `which`: the window's maximum is <= 0 (or NaN) -- for the fused activation backward
+
 template <int KH, int R, int V>
 __global__ __launch_bounds__(256) void poolrows_drop_add_fwd_kernel(const float* __restrict__ h, const float* __restrict__ res,
                                                                     float* __restrict__ out, int8_t* __restrict__ which,
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(256) void poolrows_drop_add_fwd_kernel(const float*
         float y = best;
         if (drop) y = rng_uniform(seed, offset + (uint64_t)(e + c)) >= p ? best * scale : 0.f;
         o[c] = res ? y + rv[r][c] : y;
-        wsel[c] = (int8_t)sel;
+        wsel[c] = (int8_t)(sel | (best > 0.f ? 0 : POOLROWS_NONPOS));     // bit 6: the maximum is not positive
       }
       if constexpr (V == 4) {
         *reinterpret_cast<float4*>(out + e) = float4{o[0], o[1], o[2], o[3]};
@@ -172,11 +174,14 @@ __global__ __launch_bounds__(256) void poolrows_drop_add_fwd_kernel(const float*
 
 // Backward of the pool + dropout part (the residual's gradient is dout itself): gather form, fixed order -- input row
 // rho collects g(r) = keep(r) * scale * dout(r) from the windows r = rho + PAD ... rho - PAD whose recorded row is rho.
+// neg_slope != 1: h is the output of a ReLU / LeakyReLU that the producing convolution applied in its epilogue, and that
+// activation's backward pass is folded in: an element that won a window *is* that window's maximum, so its sign is the window's
+// flag, and the collected sum is multiplied by neg_slope where it is not positive (= mpa_act_bwd on the result, bit for bit).
 template <int KH, int R, int V>
 __global__ __launch_bounds__(256) void poolrows_drop_bwd_kernel(const float* __restrict__ dout, const int8_t* __restrict__ which,
                                                                 float* __restrict__ dh, long planes, int H, int W, float p,
                                                                 float scale, const uint64_t* __restrict__ rng_state,
-                                                                uint64_t local) {
+                                                                uint64_t local, float neg_slope) {
   constexpr int PAD = KH / 2;
   const int WV = W / V, nblk = (H + R - 1) / R;
   const long items = planes * nblk * WV;
@@ -230,10 +235,13 @@ __global__ __launch_bounds__(256) void poolrows_drop_bwd_kernel(const float* __r
       for (int c = 0; c < V; ++c) {
         // window rho + PAD - d holds rho as its row d (register row r + 2 PAD - d)
         float a = 0.f;
+        bool nonpos = false;
 #pragma unroll
-        for (int d = 0; d < KH; ++d)
-          if (w[r + 2 * PAD - d][c] == d) a += g[r + 2 * PAD - d][c];
-        o[c] = a;
+        for (int d = 0; d < KH; ++d) {
+          const int wv = w[r + 2 * PAD - d][c];
+          if (wv >= 0 && (wv & (POOLROWS_NONPOS - 1)) == d) { a += g[r + 2 * PAD - d][c]; nonpos = wv & POOLROWS_NONPOS; }
+        }
+        o[c] = nonpos ? a * neg_slope : a;
       }
       const long e = base + (long)row * W;
       if constexpr (V == 4) *reinterpret_cast<float4*>(dh + e) = float4{o[0], o[1], o[2], o[3]};
@@ -533,7 +541,7 @@ int poolrows_fwd_launch(const float* h, const float* residual, float* out, int8_
 }
 template <int KH, int R>
 int poolrows_bwd_launch(const float* dout, const int8_t* which, float* dh, long planes, int H, int W, float p,
-                        const uint64_t* rng_state, uint64_t offset, hipStream_t s) {
+                        const uint64_t* rng_state, uint64_t offset, float neg_slope, hipStream_t s) {
   const float scale = 1.f / (1.f - p);
   const uintptr_t al = (uintptr_t)dout | (uintptr_t)dh | (uintptr_t)which;
   constexpr int VMAX = KH == 3 ? 4 : 2;
@@ -542,13 +550,13 @@ int poolrows_bwd_launch(const float* dout, const int8_t* which, float* dh, long 
   if (V == 4) {
     if constexpr (VMAX == 4)
       MPA_LAUNCH((poolrows_drop_bwd_kernel<KH, R, 4>), dim3(blocks_for(items)), dim3(256), 0, s, dout, which, dh, planes, H, W, p,
-                 scale, rng_state, offset);
+                 scale, rng_state, offset, neg_slope);
   } else if (V == 2) {
     MPA_LAUNCH((poolrows_drop_bwd_kernel<KH, R, 2>), dim3(blocks_for(items)), dim3(256), 0, s, dout, which, dh, planes, H, W, p,
-               scale, rng_state, offset);
+               scale, rng_state, offset, neg_slope);
   } else {
     MPA_LAUNCH((poolrows_drop_bwd_kernel<KH, R, 1>), dim3(blocks_for(items)), dim3(256), 0, s, dout, which, dh, planes, H, W, p,
-               scale, rng_state, offset);
+               scale, rng_state, offset, neg_slope);
   }
   return mpa_launch_status();
 }
@@ -662,14 +670,19 @@ int mpa_poolrows_dropout_add_fwd(const float* h, const float* residual, float* o
   if (kh == 3) return poolrows_fwd_launch<3, 15>(h, residual, out, which, (long)planes, H, W, p, rng_state, offset, (hipStream_t)stream);
   return poolrows_fwd_launch<13, 12>(h, residual, out, which, (long)planes, H, W, p, rng_state, offset, (hipStream_t)stream);
 }
-int mpa_poolrows_dropout_bwd(const float* dout, const int8_t* which, float* dh, int64_t planes, int H, int W, int kh, float p,
-                             const uint64_t* rng_state, uint64_t offset, void* stream) {
+int mpa_poolrows_dropout_act_bwd(const float* dout, const int8_t* which, float* dh, int64_t planes, int H, int W, int kh, float p,
+                                 const uint64_t* rng_state, uint64_t offset, float neg_slope, void* stream) {
   if (!dout || !which || !dh || planes < 0 || H <= 0 || W <= 0 || p < 0.f || p >= 1.f || (p > 0.f && !rng_state))
     return MPA_ERR_ARG;
   if (kh != 3 && kh != 13) return MPA_ERR_UNSUPPORTED;
   if (planes == 0) return MPA_OK;
-  if (kh == 3) return poolrows_bwd_launch<3, 15>(dout, which, dh, (long)planes, H, W, p, rng_state, offset, (hipStream_t)stream);
-  return poolrows_bwd_launch<13, 12>(dout, which, dh, (long)planes, H, W, p, rng_state, offset, (hipStream_t)stream);
+  if (kh == 3)
+    return poolrows_bwd_launch<3, 15>(dout, which, dh, (long)planes, H, W, p, rng_state, offset, neg_slope, (hipStream_t)stream);
+  return poolrows_bwd_launch<13, 12>(dout, which, dh, (long)planes, H, W, p, rng_state, offset, neg_slope, (hipStream_t)stream);
+}
+int mpa_poolrows_dropout_bwd(const float* dout, const int8_t* which, float* dh, int64_t planes, int H, int W, int kh, float p,
+                             const uint64_t* rng_state, uint64_t offset, void* stream) {
+  return mpa_poolrows_dropout_act_bwd(dout, which, dh, planes, H, W, kh, p, rng_state, offset, 1.f, stream);
 }
 int mpa_store_ptrs(const void** table, const void* const* host_ptrs, int n, void* stream) {
   if (!table || !host_ptrs || n < 0) return MPA_ERR_ARG;

@@ -256,13 +256,22 @@ class ConvActPoolDrop(nn.Sequential):
     def forward(self, x, residual=None):
         mods = list(self)
         conv, act = mods[0], mods[1]
-        h = conv(x, act.act, act.slope)
         rest = mods[2:]
         if len(rest) == 2 and isinstance(rest[0], MaxPool2d) and isinstance(rest[1], Dropout):
             (kh, kw), pool = rest[0].kernel_size, rest[0]
             if kw == 1 and kh in ops.POOLROWS_KH and pool.stride == (1, 1) and pool.padding == (kh // 2, 0):
-                # the stage's tail (pool over 3 / 13 frames, dropout, residual add) is one kernel
-                return ops.poolrows_dropout_add(h, residual, kh, rest[1].p, self.training)
+                # the stage's tail (pool over 3 / 13 frames, dropout, residual add) is one kernel -- which also applies the
+                # activation's backward pass (an element that wins a window is that window's maximum: its sign is kept with
+                # the argmax), unless a hook wants the convolution module's own gradient or the conv takes its GEMM path
+                plain = conv.kernel_size[0] == 1 or conv.kernel_size[0] != x.shape[2] or conv.padding[0] != 0
+                fuse = (plain and act.act in (ops.ACT_RELU, ops.ACT_LRELU) and torch.is_grad_enabled() and
+                        not (conv._forward_hooks or conv._backward_hooks or act._forward_hooks or act._backward_hooks))
+                if fuse:
+                    h = ops.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, act.act, act.slope, act_bwd_by_consumer=True)
+                    return ops.poolrows_dropout_add(h, residual, kh, rest[1].p, self.training,
+                                                    producer_slope=act.slope if act.act == ops.ACT_LRELU else 0.0)
+                return ops.poolrows_dropout_add(conv(x, act.act, act.slope), residual, kh, rest[1].p, self.training)
+        h = conv(x, act.act, act.slope)
         for m in rest:
             h = m(h)
         return h if residual is None else ops.add(h, residual)

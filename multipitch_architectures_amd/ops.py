@@ -352,7 +352,10 @@ class Conv2dFn(torch.autograd.Function):
     pass over y."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, act, slope, with_stats=False):
+    def forward(ctx, x, weight, bias, stride, padding, act, slope, with_stats=False, act_bwd_by_consumer=False):
+        # act_bwd_by_consumer: the activation is applied here (store epilogue) but its backward pass by the node that consumes y
+        # (poolrows_dropout_add(..., producer_slope=...)): backward() then takes the incoming gradient as d/d(pre-activation)
+        ctx.defer_act = bool(act_bwd_by_consumer)
         # no zero tensor for the gradient of the non-differentiable `partials` output: autograd would otherwise fill one per
         # BatchNorm layer and step (18 fill launches for SAUnet:L)
         ctx.set_materialize_grads(False)
@@ -417,11 +420,11 @@ class Conv2dFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dpartials=None):
         if dy is None:                     # (set_materialize_grads(False): nothing flowed into y)
-            return None, None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None, None
         x, weight, y = ctx.saved_tensors
         d, lib = ctx.desc, _lib()
         dy = _c(dy, "conv grad")
-        if ctx.act != ACT_NONE:
+        if ctx.act != ACT_NONE and not ctx.defer_act:
             g = torch.empty_like(dy)
             _chk(lib.mpa_act_bwd(_p(dy), _p(y), _p(g), dy.numel(), ctx.act, ctx.slope, _s()), "mpa_act_bwd")
             dy = g
@@ -462,7 +465,7 @@ class Conv2dFn(torch.autograd.Function):
             _chk(_probed("wgrad", d, lambda: lib.mpa_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(db),
                                                                        _p(ws), int(nbytes), _s())),
                  "mpa_conv2d_bwd_weight")
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 def conv2d_stats(x, weight, bias, stride=(1, 1), padding=(0, 0)):
@@ -470,9 +473,15 @@ def conv2d_stats(x, weight, bias, stride=(1, 1), padding=(0, 0)):
     return Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(padding), ACT_NONE, 0.0, True)
 
 
-def conv2d(x, weight, bias, stride=(1, 1), padding=(0, 0), act=ACT_NONE, slope=0.0):
+def conv2d(x, weight, bias, stride=(1, 1), padding=(0, 0), act=ACT_NONE, slope=0.0, act_bwd_by_consumer=False):
+    """act_bwd_by_consumer: see Conv2dFn.forward (only the plain convolution path takes it: the caller pairs it with
+    poolrows_dropout_add(..., producer_slope=...), whose stages are padded (kh,kw) convolutions)."""
     stride, padding = tuple(stride), tuple(padding)
     kh, kw = weight.shape[2], weight.shape[3]
+    if act_bwd_by_consumer:
+        if act not in (ACT_RELU, ACT_LRELU) or (kh > 1 and kh == x.shape[2] and padding[0] == 0):
+            raise RuntimeError("conv2d(act_bwd_by_consumer=True): a ReLU / LeakyReLU stage on the plain convolution path only")
+        return Conv2dFn.apply(x, weight, bias, stride, padding, act, slope, False, True)
     if kh > 1 and kh == x.shape[2] and padding[0] == 0 and x.is_contiguous() and weight.is_contiguous():
         B, C, H, W = x.shape
         if kw == 1 and stride[1] == 1 and padding[1] == 0:
@@ -924,7 +933,10 @@ class PoolRowsDropAddFn(torch.autograd.Function):
     position in the dropout stream as max_pool2d + dropout + add."""
 
     @staticmethod
-    def forward(ctx, h, residual, kh, p):
+    def forward(ctx, h, residual, kh, p, producer_slope=None):
+        # producer_slope: h = ReLU / LeakyReLU(conv) from conv2d(..., act_bwd_by_consumer=True): this node's backward also applies
+        # that activation's (d/dh is multiplied by the slope where h <= 0 -- the sign is kept with the argmax row)
+        ctx.producer_slope = producer_slope
         h = _c(h)
         B, C, H, W = h.shape
         if residual is not None:
@@ -954,16 +966,17 @@ class PoolRowsDropAddFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             B, C, H, W = dout.shape
             dh = torch.empty_like(dout)
-            _chk(_lib().mpa_poolrows_dropout_bwd(_p(dout), ctypes.c_void_p(which.data_ptr()), _p(dh), B * C, H, W, ctx.kh,
-                                                ctx.p, _p(ctx.state) if ctx.state is not None else None, ctx.offset,
-                                                _s()), "mpa_poolrows_dropout_bwd")
-        return dh, (dout if ctx.has_res and ctx.needs_input_grad[1] else None), None, None
+            slope = 1.0 if ctx.producer_slope is None else float(ctx.producer_slope)
+            _chk(_lib().mpa_poolrows_dropout_act_bwd(_p(dout), ctypes.c_void_p(which.data_ptr()), _p(dh), B * C, H, W, ctx.kh,
+                                                    ctx.p, _p(ctx.state) if ctx.state is not None else None, ctx.offset,
+                                                    slope, _s()), "mpa_poolrows_dropout_act_bwd")
+        return dh, (dout if ctx.has_res and ctx.needs_input_grad[1] else None), None, None, None
 
 
 POOLROWS_KH = (3, 13)      # window heights the fused kernels are built for
 
 
-def poolrows_dropout_add(h, residual, kh, p, training):
+def poolrows_dropout_add(h, residual, kh, p, training, producer_slope=None):
     """dropout(max_pool2d(h, (kh,1), (1,1), (kh//2,0)), p) [+ residual]"""
     p = float(p) if training else 0.0
     if p >= 1.0:
@@ -972,7 +985,7 @@ def poolrows_dropout_add(h, residual, kh, p, training):
         raise RuntimeError("poolrows_dropout_add expects (B, C, H, W)")
     if kh not in POOLROWS_KH:
         raise RuntimeError(f"poolrows_dropout_add is built for window heights {POOLROWS_KH}, got {kh}")
-    return PoolRowsDropAddFn.apply(h, residual, kh, p)
+    return PoolRowsDropAddFn.apply(h, residual, kh, p, producer_slope)
 
 
 class AddFn(torch.autograd.Function):

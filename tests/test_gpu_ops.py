@@ -768,6 +768,38 @@ def test_poolrows_dropout_add_matches_the_three_separate_ops(dev, shape, kh, p, 
         _close(dhf, hr.grad, 1e-6, "dh vs torch")
 
 
+@pytest.mark.parametrize("kh,act,slope", [(13, 2, 0.3), (3, 2, 0.3), (3, 1, 0.0)])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_conv_act_pool_stage_with_the_activation_backward_in_the_pool_kernel(dev, kh, act, slope, with_res):
+    """nn.Sequential(Conv2d, LeakyReLU, MaxPool2d((kh,1)), Dropout) [+ residual] (basic_cnns.py:371-385, unet_cnns.py:538-543)
+    with the activation's backward pass folded into the pool backward (conv2d(act_bwd_by_consumer=True) +
+    poolrows_dropout_add(producer_slope=...)) against the same stage with the separate mpa_act_bwd pass: an element that wins a
+    window is that window's maximum, so the sign kept with the argmax row is its own.  Same values, bit for bit, where the
+    convolution's backward kernels add in a fixed order."""
+    from multipitch_architectures_amd import ops
+    x, w, b = _rand((3, 5, 19, 12), 71), _rand((8, 5, 3, 3), 72, 0.3), _rand((8,), 73, 0.5)
+    res = _rand((3, 8, 19, 12), 74) if with_res else None
+    gy = _rand((3, 8, 19, 12), 75).to(dev)
+
+    def run(fused):
+        ops.manual_seed(77)
+        xs = [t.to(dev).requires_grad_(True) for t in (x, w, b)]
+        rg = res.to(dev).requires_grad_(True) if with_res else None
+        h = ops.conv2d(xs[0], xs[1], xs[2], (1, 1), (1, 1), act, slope, act_bwd_by_consumer=fused)
+        y = ops.poolrows_dropout_add(h, rg, kh, 0.2, True, producer_slope=(slope if fused else None))
+        y.backward(gy)
+        ops.rng_advance()
+        return [y.detach()] + [t.grad for t in xs] + ([rg.grad] if with_res else [])
+
+    got, want = run(True), run(False)
+    assert torch.equal(got[0], want[0])
+    for a_, b_, name in zip(got[1:], want[1:], ("dx", "dw", "db", "dres")):
+        _close(a_, b_, 1e-6, name)
+    assert float(got[1].abs().sum()) > 0.0 and (want[0] <= 0).any()          # (both signs occur)
+    with pytest.raises(RuntimeError):
+        ops.conv2d(x.to(dev), w.to(dev), b.to(dev), (1, 1), (1, 1), ops.ACT_SIGMOID, 0.0, act_bwd_by_consumer=True)
+
+
 @pytest.mark.parametrize("kh", [3, 13])
 def test_poolrows_dropout_add_nan_propagates_and_eval_mode(dev, kh):
     from multipitch_architectures_amd import ops
